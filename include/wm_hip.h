@@ -1,0 +1,196 @@
+/*
+ * wm_hip.h -- C-ABI of the MI355X-native WildlifeMapper inference path.
+ *
+ * The reference (lgemc/WildlifeMapper) is pure Python/PyTorch and has no FFI
+ * of its own: the boundary it exposes is a set of
+ * nn.Module call signatures.  This header is the C-ABI inserted *below* those
+ * signatures; every entry point names the reference call it replaces
+ * (paths relative to /root/reference/wildlifemapper/).  INTEGRATION.md shows
+ * the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; wm_last_error() gives
+ *     the message of the calling thread's last failure.  Nothing throws
+ *     across the ABI.
+ *   - device pointers are BORROWED (the caller, e.g. PyTorch-ROCm, owns them);
+ *     contiguous fp32, NCHW where an image-like tensor is meant.  The handle
+ *     owns packed weights and workspace, sized at create for `max_batch`.
+ *   - launches are asynchronous on the caller's stream (`hipStream_t` passed
+ *     as void*; NULL = default stream).  One handle per (device, stream);
+ *     a handle is not thread-safe.
+ *   - there is NO CPU fallback anywhere behind this ABI.
+ */
+#ifndef WM_HIP_H
+#define WM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WM_ABI_VERSION 1
+
+/* operand type of the MFMA GEMM / attention path (accumulation is fp32) */
+#define WM_PREC_BF16 0   /* north_star default: bf16 MFMA                         */
+#define WM_PREC_FP16 1   /* fp16 MFMA, same rate, 3 more mantissa bits */
+
+#define WM_MAX_GLOBAL 8
+#define WM_NUM_QUERIES 51   /* segment_anything/modeling/box_decoder.py:53 (50 + 1) */
+#define WM_NUM_LOGITS 8     /* box_decoder.py:50,68 (6 + 1 classes, + background)   */
+
+/* Encoder dims: what segment_anything/build_sam.py:19-52 passes to _build_sam.
+ * Everything else (img 1024, patch 16, window 14, out 256, HFC dim 1024 / 8
+ * heads, decoder 256 / 8 heads / depth 2 / 51 queries) is fixed by
+ * build_sam.py:266-309 and image_encoder.py:65-87. */
+typedef struct wm_config {
+    int32_t embed_dim;                        /* 1280 (vit_h) | 1024 | 768 */
+    int32_t depth;                            /* 32 | 24 | 12 */
+    int32_t num_heads;                        /* 16 | 16 | 12 */
+    int32_t num_global;                       /* 4 */
+    int32_t global_attn_indexes[WM_MAX_GLOBAL];
+    int32_t max_batch;                        /* tiles per call the workspace is sized for */
+    int32_t precision;                        /* WM_PREC_* */
+    int32_t reserved[4];
+} wm_config;
+
+typedef struct wm_handle wm_handle;
+
+/* One detection slot; WM_NUM_QUERIES of them per tile, fixed size so that the
+ * multi-GPU collation is a single fixed-size all-gather (replaces the pickle
+ * gather of segment_anything/utils/misc.py:180-220). */
+typedef struct wm_box_record {
+    float   box[4];      /* x0,y0,x1,y1 scaled to target size (build_sam.py:250-254) */
+    float   score;       /* max softmax prob over the 7 non-background columns (:232-233) */
+    int32_t label;       /* argmax column */
+    int32_t flags;       /* bit0: score > conf_thr (PostProcess keep, :239)
+                            bit1: score > score_thr (visualize_prediction.py:150)
+                            bit2: survives NMS (visualize_prediction.py:154) */
+    int32_t nms_rank;    /* position in the NMS output list (descending score), -1 if not kept */
+} wm_box_record;
+
+#define WM_FLAG_CONF 1
+#define WM_FLAG_SCORE 2
+#define WM_FLAG_NMS 4
+
+const char* wm_last_error(void);
+int wm_abi_version(void);
+
+/* ---- lifetime / weights ---------------------------------------------------
+ * Replaces model construction + load_state_dict:
+ *   segment_anything/build_sam.py:260-322 (_build_sam), visualize_prediction.py:112-115.
+ * wm_load_weight copies one state_dict tensor (fp32, host memory, names of
+ * SURVEY.md §8b, e.g. "image_encoder.blocks.3.attn.qkv.weight"); unknown names
+ * are an error, missing names are reported by wm_finalize_weights, which packs
+ * everything into device buffers (16-bit GEMM operands, fp32 vectors). */
+int wm_create(const wm_config* cfg, int device, wm_handle** out);
+int wm_destroy(wm_handle* h);
+int wm_load_weight(wm_handle* h, const char* name, const float* host_data,
+                   const int64_t* shape, int ndim);
+int wm_finalize_weights(wm_handle* h);
+
+/* ---- the path ------------------------------------------------------------- */
+
+/* MedSAM.fft, segment_anything/network.py:36-57.
+ * x (B,3,1024,1024) fp32 -> hfc (B,1,1024,1024) fp32. */
+int wm_hfc_fft(wm_handle* h, const float* x_dev, float* hfc_dev, int batch, void* stream);
+
+/* ImageEncoderViT.forward(x, x_hfc), segment_anything/modeling/image_encoder.py:123-138.
+ * x (B,3,1024,1024), x_hfc (B,1,1024,1024) -> out (B,256,64,64), all fp32. */
+int wm_encoder_forward(wm_handle* h, const float* x_dev, const float* hfc_dev,
+                       float* out_dev, int batch, void* stream);
+
+/* MaskDecoder.forward with image_pe = PromptEncoder.get_dense_pe(),
+ * segment_anything/modeling/box_decoder.py:71-107, pos_encoder.py:24-33.
+ * emb (B,256,64,64) -> pred_logits (B,51,8), pred_boxes (B,51,4) (sigmoid applied). */
+int wm_decoder_forward(wm_handle* h, const float* emb_dev, float* logits_dev,
+                       float* boxes_dev, int batch, void* stream);
+
+/* PostProcess.forward (segment_anything/build_sam.py:219-258) followed by the
+ * score cut + torchvision.ops.nms step of visualize_prediction.py:150-157, per tile.
+ * target_sizes (B,2) fp32 as build_sam.py:252-253 reads them.
+ * records: B * WM_NUM_QUERIES slots in query order. */
+int wm_postprocess_nms(wm_handle* h, const float* logits_dev, const float* boxes_dev,
+                       const float* target_sizes_dev, float conf_thr, float score_thr,
+                       float iou_thr, wm_box_record* records_dev, int batch, void* stream);
+
+/* MedSAM.forward (network.py:59-87) + post-processing in one call; hfc and the
+ * embedding stay in the handle's workspace.  logits/boxes/records may be NULL
+ * if not wanted. */
+int wm_forward(wm_handle* h, const float* x_dev, const float* target_sizes_dev,
+               float* logits_dev, float* boxes_dev, wm_box_record* records_dev,
+               int batch, void* stream);
+
+/* ---- intermediate taps (parity tests) -------------------------------------
+ * Copies the fp32 token stream (B,64,64,embed_dim) as it stood after the stem
+ * (which = -1) or after block `which` of the most recent wm_encoder_forward
+ * with taps enabled.  wm_set_tap selects which single point is captured. */
+int wm_set_tap(wm_handle* h, int which);      /* -2 = off */
+int wm_read_tap(wm_handle* h, float* out_dev, int batch, void* stream);
+
+/* ---- per-kernel timing (bench.py roofline) --------------------------------
+ * When enabled, every launch of a kernel class is bracketed by HIP events on
+ * the launch stream.  wm_profile_read synchronises and returns, per class,
+ * launches, total milliseconds and total algorithmic FLOPs/bytes since the
+ * last wm_profile_reset. */
+#define WM_KCLASS_GEMM16 0       /* 16-bit MFMA GEMM (qkv/proj/MLP/1x1 convs/embeds) */
+#define WM_KCLASS_ATTN_WIN 1
+#define WM_KCLASS_ATTN_GLOBAL 2
+#define WM_KCLASS_LAYERNORM 3
+#define WM_KCLASS_OTHER 4
+#define WM_KCLASS_COUNT 5
+typedef struct wm_kclass_stat {
+    int64_t launches;
+    double  ms;
+    double  flops;
+    double  bytes;
+} wm_kclass_stat;
+int wm_profile_enable(wm_handle* h, int on);
+int wm_profile_reset(wm_handle* h);
+int wm_profile_read(wm_handle* h, wm_kclass_stat* out /* [WM_KCLASS_COUNT] */);
+
+/* ---- single-op entry points (kernel-level parity tests) --------------------
+ * Thin launches of individual kernels on caller-provided device buffers.
+ * 16-bit buffers hold bf16 or fp16 per `precision`. */
+
+/* fp32 -> 16-bit and back */
+int wm_op_cvt_f32_to_16(const float* in_dev, void* out_dev, int64_t n, int precision, void* stream);
+int wm_op_cvt_16_to_f32(const void* in_dev, float* out_dev, int64_t n, int precision, void* stream);
+
+/* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual[(row % res_mod), N]).
+ * A, W 16-bit; bias/residual fp32 or NULL; out_f32 and/or out_16 (either may be NULL).
+ * act: 0 none, 1 GELU(erf), 2 ReLU.  res_mod <= 0 means M. */
+int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* bias_dev,
+                 const float* residual_dev, int res_mod, float* out_f32_dev, void* out_16_dev,
+                 int M, int N, int K, int act, int precision, void* stream);
+
+/* fp32 GEMM on the fp32-input MFMA, same contract (act 3 = sigmoid). */
+int wm_op_gemm32(const float* a_dev, const float* w_dev, const float* bias_dev,
+                 const float* residual_dev, float* out_dev, int M, int N, int K, int act, void* stream);
+
+/* LayerNorm over the last dim of [rows, C] fp32 (biased variance); writes fp32 and/or 16-bit. */
+int wm_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps,
+                    float* out_f32_dev, void* out_16_dev, int64_t rows, int C, int precision, void* stream);
+
+/* Attention of image_encoder.py:246-262 on a packed qkv buffer [B*4096, 3*D] (16-bit),
+ * D = heads*head_dim.  window = 14 (25 padded windows per tile, padded keys/values = qkv bias,
+ * image_encoder.py:190-194,278-285) or 0 (global 4096 keys).  rel_pos_h/w fp32
+ * [(2*size-1), head_dim].  qkv_bias fp32 [3*D] (used for the padded tokens).  out 16-bit [B*4096, D]. */
+int wm_op_encoder_attention(const void* qkv_dev, const float* qkv_bias_dev,
+                            const float* rel_pos_h_dev, const float* rel_pos_w_dev, void* out_dev,
+                            int batch, int heads, int head_dim, int window, int precision, void* stream);
+
+/* Plain multi-head attention softmax(q k^T / sqrt(hd)) v, no bias terms (HFC adaptor,
+ * image_encoder.py:500-503).  q [B,Nq,*] row stride q_stride, k/v [B,Nk,*] (16-bit). */
+int wm_op_mha16(const void* q_dev, int q_stride, const void* k_dev, int k_stride,
+                const void* v_dev, int v_stride, void* out_dev, int out_stride,
+                int batch, int heads, int head_dim, int nq, int nk, int precision, void* stream);
+
+/* fp32 attention of the decoder (transformer.py:217-240 core), q [B,Nq,heads*hd], k/v [B,Nk,heads*hd]. */
+int wm_op_mha32(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev,
+                int batch, int heads, int head_dim, int nq, int nk, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WM_HIP_H */

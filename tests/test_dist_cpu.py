@@ -1,0 +1,56 @@
+"""world_size-2 (and 3) gloo tests of the tile shard + fixed-size record all-gather (dist.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from wildlifemapper_amd import dist as wdist
+
+
+def test_shard_range_partitions():
+    for n in (1, 7, 16, 128, 129):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                s, e = wdist.shard_range(n, r, world)
+                assert e - s <= wdist.max_shard(n, world)
+                seen += list(range(s, e))
+            assert seen == list(range(n))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_tiles, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = wdist.init_from_env("gloo")
+    s, e = wdist.shard_range(n_tiles, r, w)
+    # record content encodes (tile, slot, field) so misplacement is visible
+    t = torch.arange(s, e, dtype=torch.float32).view(-1, 1, 1) * 1000 + torch.arange(51).view(1, -1, 1) * 10 + torch.arange(8).view(1, 1, -1)
+    full = wdist.all_gather_records(t.contiguous(), n_tiles, r, w)
+    want = torch.arange(n_tiles, dtype=torch.float32).view(-1, 1, 1) * 1000 + torch.arange(51).view(1, -1, 1) * 10 + torch.arange(8).view(1, 1, -1)
+    q.put((rank, bool(torch.equal(full, want)), tuple(full.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_tiles", [(2, 8), (2, 5), (3, 7)])
+def test_all_gather_records_gloo(world, n_tiles):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_tiles, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(shape == (n_tiles, 51, 8) for _, _, shape in res)

@@ -1,0 +1,233 @@
+"""Kernel-level parity (-m gpu): every HIP kernel, through the C-ABI, against a plain
+fp32 evaluation of the same operation on the same (already 16-bit-rounded) operands.
+
+Tolerances (relative L2 unless stated):
+  fp32-output kernels   1e-5   (fp32 accumulation order only)
+  16-bit-output kernels bf16 5e-3 / fp16 7e-4 (one output rounding: 2^-9 / 2^-12)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import wm_oracle as O          # checker only
+import gpu_util as G
+
+OUT16_TOL = {"bf16": 5e-3, "fp16": 7e-4}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device (run with -m 'not gpu' on CPU)")
+    torch.manual_seed(0)
+
+
+def _rnd(t, prec):
+    return t.to(G.PRECS[prec][1]).float()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_cvt_matches_torch_rounding(prec):
+    x = torch.randn(1 << 16, device=G.dev()) * 3
+    x[:4] = torch.tensor([0.0, -0.0, 1e-8, 70000.0], device=G.dev())
+    y = G.to16(x, prec)
+    want = x.clamp(-65504, 65504).to(torch.float16) if prec == "fp16" else x.to(torch.bfloat16)
+    assert torch.equal(y.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 1280), (4096, 3840, 1280), (512, 256, 2304), (8192, 1280, 5120)])
+def test_gemm16_plain(prec, M, N, K):
+    a = G.to16(torch.randn(M, K, device=G.dev()), prec)
+    w = G.to16(torch.randn(N, K, device=G.dev()) / math.sqrt(K), prec)
+    o32, o16 = G.gemm16(a, w, prec=prec, want16=True)
+    ref = a.float() @ w.float().t()
+    assert G.rel_l2(o32, ref) < 1e-5
+    assert G.rel_l2(o16.float(), ref) < OUT16_TOL[prec]
+
+
+def test_gemm16_identity_asymmetric():
+    """A = I against an asymmetric W catches a transposed or permuted C write (cdna guide §3)."""
+    n = 128
+    a = torch.zeros(n, 128, device=G.dev())
+    a[:, :n] = torch.eye(n, device=G.dev())
+    w = (torch.arange(256 * 128, device=G.dev(), dtype=torch.float32).reshape(256, 128) % 251) - 125
+    o32, _ = G.gemm16(G.to16(a, "bf16"), G.to16(w, "bf16"))
+    assert torch.equal(o32, w[:, :n].t().contiguous())
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm16_epilogue(prec, act):
+    M, N, K = 384, 256, 320
+    a = G.to16(torch.randn(M, K, device=G.dev()), prec)
+    w = G.to16(torch.randn(N, K, device=G.dev()) / math.sqrt(K), prec)
+    bias = torch.randn(N, device=G.dev())
+    res = torch.randn(128, N, device=G.dev())          # broadcast residual (rows modulo 128)
+    o32, o16 = G.gemm16(a, w, bias, res, 128, act, prec, want16=True)
+    y = a.float() @ w.float().t() + bias
+    if act == 1:
+        y = O.gelu_erf(y)
+    elif act == 2:
+        y = torch.relu(y)
+    y = y + res.repeat(M // 128, 1)
+    assert G.rel_l2(o32, y) < 2e-5
+    assert G.rel_l2(o16.float(), y) < OUT16_TOL[prec]
+
+
+def test_gemm16_inplace_residual():
+    M, N, K = 256, 128, 128
+    a = G.to16(torch.randn(M, K, device=G.dev()), "bf16")
+    w = G.to16(torch.randn(N, K, device=G.dev()) / 11, "bf16")
+    x = torch.randn(M, N, device=G.dev())
+    want = x + a.float() @ w.float().t()
+    from wildlifemapper_amd import _native as Nn
+    Nn.check(Nn.lib().wm_op_gemm16(Nn.ptr(a), Nn.ptr(w), None, Nn.ptr(x), 0, Nn.ptr(x), None, M, N, K, 0, 0, G.sp()))
+    assert G.rel_l2(x, want) < 1e-5
+
+
+def test_gemm16_rejects_ragged():
+    a = G.to16(torch.randn(100, 64, device=G.dev()), "bf16")
+    w = G.to16(torch.randn(128, 64, device=G.dev()), "bf16")
+    with pytest.raises(RuntimeError, match="multiples"):
+        G.gemm16(a, w)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(51, 8, 256, 0), (102, 4, 256, 3), (4096, 128, 256, 0), (51, 2048, 256, 2), (153, 256, 2048, 0), (64, 64, 16, 1)])
+def test_gemm32(M, N, K, act):
+    a = torch.randn(M, K, device=G.dev())
+    w = torch.randn(N, K, device=G.dev()) / math.sqrt(K)
+    bias = torch.randn(N, device=G.dev())
+    res = torch.randn(M, N, device=G.dev())
+    out = G.gemm32(a, w, bias, res, act)
+    y = (a.double() @ w.double().t() + bias.double())
+    y = {0: y, 1: 0.5 * y * (1 + torch.erf(y / math.sqrt(2))), 2: torch.relu(y), 3: torch.sigmoid(y)}[act] + res.double()
+    assert G.rel_l2(out, y) < 2e-6
+
+
+@pytest.mark.parametrize("C,eps", [(256, 1e-5), (768, 1e-6), (1024, 1e-5), (1280, 1e-6)])
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_layernorm(C, eps, prec):
+    rows = 1000
+    x = torch.randn(rows, C, device=G.dev()) * 3 + 0.7
+    g = torch.rand(C, device=G.dev()) + 0.5
+    b = torch.randn(C, device=G.dev())
+    o32, o16 = G.layernorm(x, g, b, eps, prec, want16=True)
+    ref = O.layer_norm(x.cpu(), g.cpu(), b.cpu(), eps)
+    assert (o32.cpu() - ref).abs().max().item() < 2e-5
+    assert G.rel_l2(o16.float(), ref) < OUT16_TOL[prec]
+
+
+# ---------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------
+def _ref_encoder_attention(qkv, bias16, rel_h, rel_w, B, heads, hd, window, prec):
+    """fp32 evaluation of image_encoder.py:246-262 (+ window partition :190-199) from a 16-bit-rounded
+    packed qkv; padded tokens carry the (16-bit rounded) qkv bias, P is rounded before P.V like the kernel."""
+    D = heads * hd
+    x = qkv.float().reshape(B, 64, 64, 3 * D)
+    if window:
+        xw, n = O.to_windows(x - bias16, window)
+        xw = xw + bias16
+        S = window
+    else:
+        xw, n, S = x, 0, 64
+    Bp = xw.shape[0]
+    t = xw.reshape(Bp, S * S, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    Rh = O.rel_pos_table(S, _rnd(rel_h, prec))
+    Rw = O.rel_pos_table(S, _rnd(rel_w, prec))
+    a = (q @ k.transpose(-1, -2)) * (hd ** -0.5)
+    rq = q.reshape(Bp, heads, S, S, hd)
+    rh = torch.einsum("bnhwc,hkc->bnhwk", rq, Rh)
+    rw = torch.einsum("bnhwc,wkc->bnhwk", rq, Rw)
+    a = (a.view(Bp, heads, S, S, S, S) + rh[..., :, None] + rw[..., None, :]).view(Bp, heads, S * S, S * S)
+    p = _rnd(a.softmax(-1), prec)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(Bp, S, S, D)
+    if window:
+        o = O.from_windows(o, window, n, 64)
+    return o.reshape(B * 4096, D)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("heads,hd", [(2, 80), (3, 64)])
+def test_window_attention(prec, heads, hd):
+    B, D = 2, heads * hd
+    dev = G.dev()
+    qkv = G.to16(torch.randn(B * 4096, 3 * D, device=dev), prec)
+    bias = torch.randn(3 * D, device=dev) * 0.5
+    rel_h = torch.randn(27, hd, device=dev) * 0.3
+    rel_w = torch.randn(27, hd, device=dev) * 0.3
+    out = G.encoder_attention(qkv, bias, rel_h, rel_w, B, heads, hd, 14, prec)
+    ref = _ref_encoder_attention(qkv, _rnd(bias, prec), rel_h, rel_w, B, heads, hd, 14, prec)
+    assert G.rel_l2(out.float(), ref) < 2 * OUT16_TOL[prec]
+    assert (out.float() - ref).abs().max().item() < (0.06 if prec == "bf16" else 0.01)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("heads,hd", [(2, 80), (2, 64)])
+def test_global_attention_relpos(prec, heads, hd):
+    B, D = 1, heads * hd
+    dev = G.dev()
+    qkv = G.to16(torch.randn(B * 4096, 3 * D, device=dev), prec)
+    bias = torch.zeros(3 * D, device=dev)
+    rel_h = torch.randn(127, hd, device=dev) * 0.3
+    rel_w = torch.randn(127, hd, device=dev) * 0.3
+    out = G.encoder_attention(qkv, bias, rel_h, rel_w, B, heads, hd, 0, prec)
+    ref = _ref_encoder_attention(qkv, _rnd(bias, prec), rel_h, rel_w, B, heads, hd, 0, prec)
+    assert G.rel_l2(out.float(), ref) < 2 * OUT16_TOL[prec]
+
+
+def test_global_attention_forces_rescale():
+    """One key row spiked against the queries so the running max jumps at a late tile (online-softmax
+    rescale branch; cdna guide rule 26)."""
+    heads, hd, prec, dev = 1, 80, "bf16", G.dev()
+    D = heads * hd
+    x = torch.randn(4096, 3 * D, device=dev) * 0.3
+    x[3000, D:2 * D] = x[100, 0:D] * 40          # key 3000 aligned with query 100
+    qkv = G.to16(x, prec)
+    zero = torch.zeros(3 * D, device=dev)
+    rel = torch.zeros(127, hd, device=dev)
+    out = G.encoder_attention(qkv, zero, rel, rel, 1, heads, hd, 0, prec)
+    ref = _ref_encoder_attention(qkv, zero, rel, rel, 1, heads, hd, 0, prec)
+    assert G.rel_l2(out.float(), ref) < 2 * OUT16_TOL[prec]
+    assert (out.float()[100] - ref[100]).abs().max().item() < 0.05
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_mha16_hfc_shape(prec):
+    """HFC cross-attention geometry: 8 heads x 128, q from one buffer, k/v interleaved in another."""
+    B, heads, hd, n = 1, 8, 128, 4096
+    dev = G.dev()
+    q = G.to16(torch.randn(B * n, heads * hd, device=dev), prec)
+    kv = G.to16(torch.randn(B * n, 2 * heads * hd, device=dev), prec)
+    from wildlifemapper_amd import _native as Nn
+    out = torch.empty((B * n, heads * hd), device=dev, dtype=G.PRECS[prec][1])
+    Nn.check(Nn.lib().wm_op_mha16(Nn.ptr(q), heads * hd, Nn.ptr(kv), 2 * heads * hd, C_off(kv, heads * hd), 2 * heads * hd,
+                                  Nn.ptr(out), heads * hd, B, heads, hd, n, n, G.PRECS[prec][0], G.sp()))
+    qf = q.float().view(B, n, heads, hd).permute(0, 2, 1, 3)
+    kf = kv.float()[:, :heads * hd].reshape(B, n, heads, hd).permute(0, 2, 1, 3)
+    vf = kv.float()[:, heads * hd:].reshape(B, n, heads, hd).permute(0, 2, 1, 3)
+    p = _rnd(((qf @ kf.transpose(-1, -2)) / math.sqrt(hd)).softmax(-1), prec)
+    ref = (p @ vf).permute(0, 2, 1, 3).reshape(B * n, heads * hd)
+    assert G.rel_l2(out.float(), ref) < 2 * OUT16_TOL[prec]
+
+
+def C_off(t, elems):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + elems * t.element_size())
+
+
+@pytest.mark.parametrize("nq,nk,heads,hd", [(51, 4096, 8, 16), (4096, 51, 8, 16), (51, 51, 8, 32), (7, 130, 2, 16)])
+def test_mha32(nq, nk, heads, hd):
+    B, dev = 2, G.dev()
+    q = torch.randn(B, nq, heads * hd, device=dev)
+    k = torch.randn(B, nk, heads * hd, device=dev)
+    v = torch.randn(B, nk, heads * hd, device=dev)
+    out = G.mha32(q, k, v, heads)
+    ref = O.mha_core(q.cpu(), k.cpu(), v.cpu(), heads, O.OracleCfg())
+    assert (out.cpu() - ref).abs().max().item() < 2e-5

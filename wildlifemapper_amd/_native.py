@@ -1,0 +1,106 @@
+"""ctypes binding of libwm_hip.so (include/wm_hip.h).  No fallback: if the
+library is missing or a call fails this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch  # noqa: F401  (must be imported first so both share one HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwm_hip.so")
+
+PREC_BF16, PREC_FP16 = 0, 1
+PREC_BY_NAME = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16}
+NUM_QUERIES, NUM_LOGITS = 51, 8
+KCLASS_NAMES = ("gemm16", "attn_window", "attn_global", "layernorm", "other")
+FLAG_CONF, FLAG_SCORE, FLAG_NMS = 1, 2, 4
+
+
+class WmConfig(C.Structure):
+    _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32),
+                ("num_global", C.c_int32), ("global_attn_indexes", C.c_int32 * 8),
+                ("max_batch", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class WmBoxRecord(C.Structure):
+    _fields_ = [("box", C.c_float * 4), ("score", C.c_float), ("label", C.c_int32),
+                ("flags", C.c_int32), ("nms_rank", C.c_int32)]
+
+
+class WmKclassStat(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+# every symbol include/wm_hip.h declares: name -> (restype, argtypes)
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+SYMBOLS = {
+    "wm_last_error": (C.c_char_p, []),
+    "wm_abi_version": (_I, []),
+    "wm_create": (_I, [C.POINTER(WmConfig), _I, C.POINTER(_P)]),
+    "wm_destroy": (_I, [_P]),
+    "wm_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_L), _I]),
+    "wm_finalize_weights": (_I, [_P]),
+    "wm_hfc_fft": (_I, [_P, _P, _P, _I, _P]),
+    "wm_encoder_forward": (_I, [_P, _P, _P, _P, _I, _P]),
+    "wm_decoder_forward": (_I, [_P, _P, _P, _P, _I, _P]),
+    "wm_postprocess_nms": (_I, [_P, _P, _P, _P, _F, _F, _F, _P, _I, _P]),
+    "wm_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "wm_set_tap": (_I, [_P, _I]),
+    "wm_read_tap": (_I, [_P, _P, _I, _P]),
+    "wm_profile_enable": (_I, [_P, _I]),
+    "wm_profile_reset": (_I, [_P]),
+    "wm_profile_read": (_I, [_P, C.POINTER(WmKclassStat)]),
+    "wm_op_cvt_f32_to_16": (_I, [_P, _P, _L, _I, _P]),
+    "wm_op_cvt_16_to_f32": (_I, [_P, _P, _L, _I, _P]),
+    "wm_op_gemm16": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm_op_gemm32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "wm_op_layernorm": (_I, [_P, _P, _P, _F, _P, _P, _L, _I, _I, _P]),
+    "wm_op_encoder_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm_op_mha16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "wm_op_mha32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libwm_hip.so once.  Raises RuntimeError if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)       # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if l.wm_abi_version() != 1:
+            raise RuntimeError("libwm_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = lib().wm_last_error()
+        raise RuntimeError("wm_hip: " + (msg.decode() if msg else f"status {status}"))
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device: Optional[torch.device] = None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the HIP path needs a ROCm device tensor "
+                           "(there is no CPU fallback in wildlifemapper_amd)")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError(f"{what}: expected a contiguous float32 tensor, got {t.dtype}, contiguous={t.is_contiguous()}")

@@ -1,0 +1,484 @@
+// Flash-style multi-head attention on MFMA 32x32x16 (bf16 / fp16), gfx950.
+//
+// Two kernels share the per-wave core below:
+//   attn_global_kernel  - 4096 (or any multiple of 64) keys per head, optional
+//                         decomposed rel-pos bias: the 4 global blocks
+//                         (image_encoder.py:246-262, 347-383) and, without the
+//                         bias, the HFC cross-attention (image_encoder.py:500-503).
+//   attn_window_kernel  - 14x14 windows with zero-padded tokens that still act
+//                         as keys/values (image_encoder.py:190-199, 265-311).
+//
+// Per wave: 32 query rows, scores computed TRANSPOSED (S^T = K Q^T) so that a
+// lane owns one query column: its 32x32 accumulator registers are that query's
+// scores for 16 of the tile's 32 keys, the partner lane (lane^32) holds the other
+// 16.  Softmax is therefore lane-local plus one cross-half exchange, and the
+// exponentiated tile is already the B operand of the P*V product
+// (O^T = V^T P^T, cdna_hip_programming.md §3 "An accumulator tile as the next
+// MFMA's operand"), whose A operand V^T comes from the row-major V tile in LDS
+// through ds_read_b64_tr_b16 (T10).
+//
+// The rel-pos bias is never materialised per (query,key) pair in memory:
+//   bias[q,(kh,kw)] = q.Rh[qh-kh+S-1] + q.Rw[qw-kw+S-1]   (unscaled q, :376-381)
+// For global attention a key tile is one grid row (kh fixed, kw = 0..63), so the
+// kw-term is the same 64-vector for every tile (kept in registers, used as the
+// MFMA accumulator's initial value) and the kh-term is one scalar per tile.
+// Both are produced in the prologue by MFMA products Q x table^T.
+#pragma once
+#include "wm_common.h"
+
+namespace wm {
+
+struct AttnArgs {
+    const u16* q; const u16* k; const u16* v;   // 16-bit, row = token
+    u16* out;
+    int q_stride, k_stride, v_stride, out_stride;   // elements between consecutive tokens
+    int nq, nk;                                     // tokens per image (queries / keys)
+    float scale;                                    // head_dim^-0.5
+    const float* rel_h; const float* rel_w;         // [2*S-1, HD] fp32 or null
+    const float* qkv_bias;                          // window kernel: [3*D] fp32 (padded tokens)
+    int heads;
+};
+
+template <int HD> struct AttnGeom {
+    static constexpr int KS = HD * 2 + 16;                      // K row stride (bytes): odd multiple of 16 B
+    static constexpr int VS = (HD == 128) ? 320 : 192;          // V row stride (bytes): odd multiple of 64 B
+    static constexpr int NKS = HD / 16;                         // QK^T k-steps
+    static constexpr int NDT = (HD + 31) / 32;                  // 32-row O^T tiles
+    static constexpr int CH = HD / 8;                           // 16-byte chunks per row
+};
+
+template <class T>
+__device__ __forceinline__ typename T::vec8 lds_read_v8(const char* p) {
+    return *(const typename T::vec8*)p;
+}
+
+// V^T fragment for one 32x32x16 k-step: two transposed reads of 4 keys x 16 dims.
+template <class T>
+__device__ __forceinline__ typename T::vec8 lds_read_vT(const char* p_first, int second_off) {
+    typedef __attribute__((address_space(3))) s16x4* lptr;
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p_first));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p_first + second_off));
+    s16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return __builtin_bit_cast(typename T::vec8, r);
+}
+
+// Online-softmax state of one wave (32 queries, lane = query column + 32*half).
+template <int NDT> struct SoftmaxState {
+    float m;          // running max (log2 domain)
+    float l;          // running sum, this lane's half of the keys only
+    f32x16 o[NDT];    // O^T accumulators
+    __device__ __forceinline__ void init() {
+        m = -1e30f; l = 0.f;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
+    }
+};
+
+// One key tile of NT*32 keys.  s[t] hold the raw accumulators (bias/scale already
+// folded so that log2-domain score = c1 * s).  kvalid: number of valid keys in the
+// tile (keys >= kvalid are masked).  sV: LDS address of the tile's V rows.
+template <class T, int HD, int NT>
+__device__ __forceinline__ void softmax_pv(SoftmaxState<AttnGeom<HD>::NDT>& st, f32x16 (&s)[NT],
+                                           float c1, int kvalid, const char* sV, int lane) {
+    using G = AttnGeom<HD>;
+    const int h = lane >> 5;
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = s[t][r] * c1;
+            if (key >= kvalid) v = -1e30f;
+            s[t][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(st.m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(st.m - m_new);
+    st.m = m_new;
+    float ls = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(s[t][r] - m_new);
+            s[t][r] = pv;
+            ls += pv;
+        }
+    st.l = st.l * alpha + ls;
+#pragma unroll
+    for (int dt = 0; dt < G::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
+
+    // P^T fragments -> O^T += V^T P^T.  k-step ks covers keys 16*ks .. 16*ks+15 of the tile.
+    const int g = lane >> 4;
+    // transposed-read address: group g = 16-lane group; half h = g>>1 picks keys +4h, (g&1) picks dims +16
+    const int lq = (lane & 15) >> 2, lp = lane & 3;
+    const int v_lane_off = (4 * (g >> 1) + lq) * G::VS + (16 * (g & 1) + 4 * lp) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2 * NT; ++ks) {
+        typename T::vec8 pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] = T::from_f32(s[ks >> 1][8 * (ks & 1) + j]);
+#pragma unroll
+        for (int dt = 0; dt < G::NDT; ++dt) {
+            const char* p = sV + (16 * ks) * G::VS + dt * 64 + v_lane_off;
+            typename T::vec8 va = lds_read_vT<T>(p, 8 * G::VS);
+            st.o[dt] = T::mfma32(va, pb, st.o[dt]);
+        }
+    }
+}
+
+// S^T[t] += K[tile rows 32t..32t+31] * Q^T over HD, K rows in LDS with stride KS.
+template <class T, int HD, int NT>
+__device__ __forceinline__ void qk_tile(f32x16 (&s)[NT], const typename T::vec8 (&qf)[AttnGeom<HD>::NKS],
+                                        const char* sK, int lane) {
+    using G = AttnGeom<HD>;
+    const int r31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            typename T::vec8 kf = lds_read_v8<T>(sK + (32 * t + r31) * G::KS + (16 * ks + 8 * h) * 2);
+            s[t] = T::mfma32(kf, qf[ks], s[t]);
+        }
+}
+
+// Normalise and store O^T: lane (c = lane&31, h) holds dims 32dt + (r&3) + 8(r>>2) + 4h of query c.
+template <class T, int HD>
+__device__ __forceinline__ void store_out(SoftmaxState<AttnGeom<HD>::NDT>& st, u16* out_row, int lane, bool valid) {
+    using G = AttnGeom<HD>;
+    const int h = lane >> 5;
+    const float l = st.l + __shfl_xor(st.l, 32, 64);
+    const float inv = 1.0f / l;
+    if (!valid) return;
+#pragma unroll
+    for (int dt = 0; dt < G::NDT; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int d = 32 * dt + 8 * rg + 4 * h;
+            if (d < HD) {
+                typename T::vec4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = T::from_f32(st.o[dt][4 * rg + j] * inv);
+                *(typename T::vec4*)(out_row + d) = o;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
+// Global attention (key tile = 64 keys = one grid row when REL)
+// grid (nq/128, heads, batch), 256 threads.
+// ---------------------------------------------------------------------------
+template <int HD, bool REL> struct GlobalLds {
+    using G = AttnGeom<HD>;
+    static constexpr int WAVE_F = 32 * 65;                                    // floats per wave (padded staging)
+    static constexpr int RELH_BYTES = REL ? 4 * WAVE_F * 4 : 0;              // [wave][kh][query] fp32, aliased with [query][65] staging
+    static constexpr int K_BYTES = 64 * G::KS, V_BYTES = 64 * G::VS;
+    static constexpr int KV_OFF = RELH_BYTES;
+    static constexpr int TOTAL = RELH_BYTES + 2 * (K_BYTES + V_BYTES);
+};
+
+template <class T, int HD, bool REL>
+__global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
+    using G = AttnGeom<HD>;
+    using L = GlobalLds<HD, REL>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float c1 = p.scale * 1.44269504088896340736f;
+
+    const u16* qb = p.q + ((size_t)b * p.nq) * p.q_stride + head * HD;
+    const u16* kb = p.k + ((size_t)b * p.nk) * p.k_stride + head * HD;
+    const u16* vb = p.v + ((size_t)b * p.nk) * p.v_stride + head * HD;
+
+    // Q fragments (B operand): lane holds Q[q0+c][16ks + 8h .. +7]
+    typename T::vec8 qf[G::NKS];
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks)
+        qf[ks] = *(const typename T::vec8*)(qb + (size_t)(q0 + c) * p.q_stride + 16 * ks + 8 * h);
+
+    char* sKV = smem + L::KV_OFF;
+    f32x16 relw[2];
+    float* sRelH = (float*)smem + wave * (32 * 65);
+
+    if constexpr (REL) {
+        // ---- prologue: rel_w (registers) and rel_h (LDS) for this wave's 32 queries ----
+        // table image: 128 rows x HD 16-bit, row stride KS, rows >= 127 zero
+        const int qh = q0 >> 6, qw0 = q0 & 63;
+        const float inv_scale = 1.0f / p.scale;
+        char* sTab = sKV;
+        float* sT = (float*)smem + wave * (32 * 65);          // [query c][65] fp32 staging (padded: conflict-free)
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            const float* tab = which == 0 ? p.rel_w : p.rel_h;
+            __syncthreads();
+            for (int e = tid; e < 128 * (HD / 4); e += 256) {
+                const int row = e / (HD / 4), c4 = e % (HD / 4);
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < 127) v = *(const f32x4*)(tab + (size_t)row * HD + c4 * 4);
+                typename T::vec4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+                *(typename T::vec4*)(sTab + row * G::KS + c4 * 8) = o;
+            }
+            __syncthreads();
+            if (which == 0) {
+                // T_w^T[i][c] = Rw[i].q_c for i in two passes of 64; pick i = qw + 63 - kw
+                const int qw = qw0 + c;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) relw[t][r] = 0.f;
+#pragma unroll 1
+                for (int pass = 0; pass < 2; ++pass) {
+                    f32x16 acc[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                    qk_tile<T, HD, 2>(acc, qf, sTab + pass * 64 * G::KS, lane);
+                    // stage as [c][i_local]
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int il = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            sT[c * 65 + il] = acc[t][r];
+                        }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same-wave LDS RAW
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int kw = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            const int idx = qw + 63 - kw;
+                            if ((idx >> 6) == pass) relw[t][r] = sT[c * 65 + (idx & 63)] * inv_scale;
+                        }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                }
+            } else {
+                // T_h^T[kh][c] = Rh[qh + 63 - kh].q_c : A rows taken in reversed order
+                f32x16 acc[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                const int r31 = lane & 31;
+#pragma unroll
+                for (int ks = 0; ks < G::NKS; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int row = qh + 63 - (32 * t + r31);
+                        typename T::vec8 kf = lds_read_v8<T>(sTab + row * G::KS + (16 * ks + 8 * h) * 2);
+                        acc[t] = T::mfma32(kf, qf[ks], acc[t]);
+                    }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kh = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        sRelH[kh * 32 + c] = acc[t][r] * inv_scale;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- main loop over key tiles of 64 ----
+    const int ntiles = p.nk / 64;
+    constexpr int NCH = 64 * G::CH;                 // 16-B chunks per K (or V) tile
+    constexpr int PER = (NCH + 255) / 256;
+    s16x8 kreg[PER], vreg[PER];
+
+    auto issue = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * 256;
+            if (e < NCH) {
+                const int key = e / G::CH, ch = e % G::CH;
+                kreg[i] = *(const s16x8*)(kb + (size_t)(tile * 64 + key) * p.k_stride + ch * 8);
+                vreg[i] = *(const s16x8*)(vb + (size_t)(tile * 64 + key) * p.v_stride + ch * 8);
+            }
+        }
+    };
+    auto commit = [&](int buf) {
+        char* sK = sKV + buf * (L::K_BYTES + L::V_BYTES);
+        char* sV = sK + L::K_BYTES;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * 256;
+            if (e < NCH) {
+                const int key = e / G::CH, ch = e % G::CH;
+                *(s16x8*)(sK + key * G::KS + ch * 16) = kreg[i];
+                *(s16x8*)(sV + key * G::VS + ch * 16) = vreg[i];
+            }
+        }
+    };
+
+    SoftmaxState<G::NDT> st;
+    st.init();
+    issue(0);
+    commit(0);
+    __syncthreads();
+
+    for (int j = 0; j < ntiles; ++j) {
+        const int buf = j & 1;
+        if (j + 1 < ntiles) issue(j + 1);
+        const char* sK = sKV + buf * (L::K_BYTES + L::V_BYTES);
+        const char* sV = sK + L::K_BYTES;
+        f32x16 s[2];
+        if constexpr (REL) {
+            const float rh = sRelH[j * 32 + c];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = relw[t][r] + rh;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+        }
+        qk_tile<T, HD, 2>(s, qf, sK, lane);
+        softmax_pv<T, HD, 2>(st, s, c1, 64, sV, lane);
+        if (j + 1 < ntiles) commit(buf ^ 1);
+        __syncthreads();
+    }
+    u16* orow = p.out + ((size_t)b * p.nq + q0 + c) * p.out_stride + head * HD;
+    store_out<T, HD>(st, orow, lane, true);
+}
+
+// ---------------------------------------------------------------------------
+// Window attention: one workgroup per (tile, window, head); all 196 keys of the
+// window (incl. padded tokens, whose k/v are the qkv bias) resident in LDS.
+// grid (25, heads, batch), 256 threads; each wave takes query blocks w, w+4.
+// ---------------------------------------------------------------------------
+template <int HD> struct WindowLds {
+    using G = AttnGeom<HD>;
+    static constexpr int NKEY = 224;                                       // 196 padded to 7 x 32
+    static constexpr int K_BYTES = NKEY * G::KS, V_BYTES = NKEY * G::VS;
+    static constexpr int TAB_BYTES = 64 * G::KS;                           // rel_h rows 0..26, rel_w rows 32..58
+    static constexpr int T_BYTES = 4 * 32 * 65 * 4;                        // per wave [query][65] fp32
+    static constexpr int K_OFF = 0, V_OFF = K_BYTES, TAB_OFF = V_OFF + V_BYTES, T_OFF = TAB_OFF + TAB_BYTES;
+    static constexpr int TOTAL = T_OFF + T_BYTES;
+};
+
+template <class T, int HD>
+__global__ __launch_bounds__(256, 1) void attn_window_kernel(AttnArgs p) {
+    using G = AttnGeom<HD>;
+    using L = WindowLds<HD>;
+    constexpr int WS = 14, GRID = 64, NWIN = 5, NTOK = WS * WS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int win = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int wy = win / NWIN, wx = win % NWIN;
+    const int D = p.heads * HD;
+    const float c1 = p.scale * 1.44269504088896340736f;
+    const float inv_scale = 1.0f / p.scale;
+
+    char* sK = smem + L::K_OFF;
+    char* sV = smem + L::V_OFF;
+    char* sTab = smem + L::TAB_OFF;
+    float* sT = (float*)(smem + L::T_OFF) + wave * (32 * 65);
+
+    const u16* base = p.q + ((size_t)b * GRID * GRID) * p.q_stride + head * HD;   // packed qkv: q at +0, k at +D, v at +2D
+
+    // ---- stage K, V (all 224 rows; rows >= 196 zero) and the two rel-pos tables ----
+    for (int e = tid; e < L::NKEY * G::CH; e += 256) {
+        const int key = e / G::CH, ch = e % G::CH;
+        s16x8 kv8 = s16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv8 = kv8;
+        if (key < NTOK) {
+            const int y = wy * WS + key / WS, x = wx * WS + key % WS;
+            if (y < GRID && x < GRID) {
+                const u16* row = base + (size_t)(y * GRID + x) * p.q_stride;
+                kv8 = *(const s16x8*)(row + D + ch * 8);
+                vv8 = *(const s16x8*)(row + 2 * D + ch * 8);
+            } else {
+                // zero-padded token after norm1 -> qkv = bias (image_encoder.py:190-194, 281)
+                typename T::vec8 tk, tv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    tk[j] = T::from_f32(p.qkv_bias[D + head * HD + ch * 8 + j]);
+                    tv[j] = T::from_f32(p.qkv_bias[2 * D + head * HD + ch * 8 + j]);
+                }
+                kv8 = __builtin_bit_cast(s16x8, tk);
+                vv8 = __builtin_bit_cast(s16x8, tv);
+            }
+        }
+        *(s16x8*)(sK + key * G::KS + ch * 16) = kv8;
+        *(s16x8*)(sV + key * G::VS + ch * 16) = vv8;
+    }
+    for (int e = tid; e < 64 * (HD / 4); e += 256) {
+        const int row = e / (HD / 4), c4 = e % (HD / 4);
+        const int tr = row & 31;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tr < 2 * WS - 1) v = *(const f32x4*)((row < 32 ? p.rel_h : p.rel_w) + (size_t)tr * HD + c4 * 4);
+        typename T::vec4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+        *(typename T::vec4*)(sTab + row * G::KS + c4 * 8) = o;
+    }
+    __syncthreads();
+
+    for (int qblk = wave; qblk < 7; qblk += 4) {
+        const int qi = qblk * 32 + c;                     // query slot in the window (0..223)
+        const int qh = qi / WS, qw = qi % WS;
+        const int y = wy * WS + qh, x = wx * WS + qw;
+        const bool qvalid = (qi < NTOK) && (y < GRID) && (x < GRID);
+        const size_t tok = qvalid ? (size_t)(y * GRID + x) : 0;
+        typename T::vec8 qf[G::NKS];
+#pragma unroll
+        for (int ks = 0; ks < G::NKS; ++ks)
+            qf[ks] = *(const typename T::vec8*)(base + tok * p.q_stride + 16 * ks + 8 * h);
+
+        // T[c][i]: i<32 -> q.rel_h[i], i>=32 -> q.rel_w[i-32]  (one 64-row "key tile" of table rows)
+        {
+            f32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            qk_tile<T, HD, 2>(acc, qf, sTab, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int il = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    sT[c * 65 + il] = acc[t][r] * inv_scale;
+                }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+
+        SoftmaxState<G::NDT> st;
+        st.init();
+#pragma unroll 1
+        for (int j = 0; j < 7; ++j) {
+            f32x16 s[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int kh = key / WS, kw = key - kh * WS;
+                float bias = 0.f;
+                if (key < NTOK && qi < NTOK) bias = sT[c * 65 + (qh - kh + WS - 1)] + sT[c * 65 + 32 + (qw - kw + WS - 1)];
+                s[0][r] = bias;
+            }
+            qk_tile<T, HD, 1>(s, qf, sK + j * 32 * G::KS, lane);
+            softmax_pv<T, HD, 1>(st, s, c1, NTOK - 32 * j, sV + j * 32 * G::VS, lane);
+        }
+        u16* orow = p.out + ((size_t)b * GRID * GRID + tok) * p.out_stride + head * HD;
+        store_out<T, HD>(st, orow, lane, qvalid);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+}
+
+}  // namespace wm

@@ -1,0 +1,150 @@
+// Decoder-side fp32 kernels: small multi-head attention and PostProcess + NMS.
+#pragma once
+#include "wm_common.h"
+#include "../../include/wm_hip.h"
+
+namespace wm {
+
+// ---------------------------------------------------------------------------
+// softmax(q k^T / sqrt(hd)) v in fp32 (transformer.py:225-238).  One wave per
+// (tile, head, query); lanes stride over keys with a per-lane online softmax,
+// merged across the wave at the end.  q [B,Nq,heads*HD], k/v [B,Nk,heads*HD].
+// grid (Nq, heads, B), 64 threads.
+// ---------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(64) void mha32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                   const float* __restrict__ v, float* __restrict__ out,
+                                                   int nq, int nk, int heads) {
+    const int lane = threadIdx.x;
+    const int qi = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int C = heads * HD;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const float* qp = q + ((size_t)b * nq + qi) * C + head * HD;
+    float qv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+        const f32x4 t = *(const f32x4*)(qp + d);
+        qv[d] = t[0]; qv[d + 1] = t[1]; qv[d + 2] = t[2]; qv[d + 3] = t[3];
+    }
+    float m = -1e30f, l = 0.f, acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+    for (int key = lane; key < nk; key += 64) {
+        const float* kp = k + ((size_t)b * nk + key) * C + head * HD;
+        const float* vp = v + ((size_t)b * nk + key) * C + head * HD;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const f32x4 t = *(const f32x4*)(kp + d);
+            s += qv[d] * t[0] + qv[d + 1] * t[1] + qv[d + 2] * t[2] + qv[d + 3] * t[3];
+        }
+        s *= scale;
+        const float mn = fmaxf(m, s);
+        const float a = expf(m - mn), pe = expf(s - mn);
+        l = l * a + pe;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const f32x4 t = *(const f32x4*)(vp + d);
+            acc[d] = acc[d] * a + pe * t[0];
+            acc[d + 1] = acc[d + 1] * a + pe * t[1];
+            acc[d + 2] = acc[d + 2] * a + pe * t[2];
+            acc[d + 3] = acc[d + 3] * a + pe * t[3];
+        }
+        m = mn;
+    }
+    const float M = wave_max(m);
+    const float f = expf(m - M);          // lanes that saw no key: m = -1e30 -> f = 0
+    const float L = wave_sum(l * f);
+    float* op = out + ((size_t)b * nq + qi) * C + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        const float o = wave_sum(acc[d] * f);
+        if (lane == 0) op[d] = o / L;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// PostProcess (build_sam.py:219-258) + score cut and greedy NMS
+// (visualize_prediction.py:150-157; torchvision.ops.nms semantics: stable
+// descending sort, suppress when IoU > thr).  One 64-lane wave per tile, lane =
+// query slot.  Arithmetic is kept un-contracted so box/IoU values match a plain
+// fp32 CPU evaluation bit for bit.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void postprocess_nms_kernel(const float* __restrict__ logits,
+                                                             const float* __restrict__ boxes,
+                                                             const float* __restrict__ target_sizes,
+                                                             float conf_thr, float score_thr, float iou_thr,
+                                                             wm_box_record* __restrict__ rec) {
+#pragma clang fp contract(off)
+    constexpr int NQ = WM_NUM_QUERIES, NL = WM_NUM_LOGITS;
+    __shared__ float sx0[64], sy0[64], sx1[64], sy1[64], sarea[64], sscore[64];
+    __shared__ int sorder[64], scand[64], sdead[64];
+    const int b = blockIdx.x, i = threadIdx.x;
+    const bool live = i < NQ;
+    float score = 0.f; int label = 0;
+    float x0 = 0.f, y0 = 0.f, x1 = 0.f, y1 = 0.f;
+    if (live) {
+        const float* lg = logits + ((size_t)b * NQ + i) * NL;
+        float mx = lg[0];
+#pragma unroll
+        for (int j = 1; j < NL; ++j) mx = fmaxf(mx, lg[j]);
+        float e[NL], sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { e[j] = expf(lg[j] - mx); sum += e[j]; }
+        score = e[0] / sum;                         // max over the first NL-1 columns, first index wins ties
+#pragma unroll
+        for (int j = 1; j < NL - 1; ++j) {
+            const float pj = e[j] / sum;
+            if (pj > score) { score = pj; label = j; }
+        }
+        const float* bx = boxes + ((size_t)b * NQ + i) * 4;
+        const float cx = bx[0], cy = bx[1], w = bx[2], h = bx[3];
+        const float sw = target_sizes[b * 2 + 0], sh = target_sizes[b * 2 + 1];   // build_sam.py:252-253
+        x0 = (cx - 0.5f * w) * sw; y0 = (cy - 0.5f * h) * sh;
+        x1 = (cx + 0.5f * w) * sw; y1 = (cy + 0.5f * h) * sh;
+    }
+    const bool conf = live && score > conf_thr;
+    const bool cand = conf && score > score_thr;
+    sx0[i] = x0; sy0[i] = y0; sx1[i] = x1; sy1[i] = y1;
+    sarea[i] = (x1 - x0) * (y1 - y0);
+    sscore[i] = score; scand[i] = cand ? 1 : 0; sdead[i] = 0;
+    __syncthreads();
+    // rank among candidates: descending score, ties by ascending slot (stable sort)
+    int rank = 0, ncand = 0;
+    for (int j = 0; j < NQ; ++j) {
+        if (scand[j]) {
+            ++ncand;
+            if (sscore[j] > score || (sscore[j] == score && j < i)) ++rank;
+        }
+    }
+    if (cand) sorder[rank] = i;
+    __syncthreads();
+    int nms_rank = -1, kept = 0;
+    for (int r = 0; r < ncand; ++r) {
+        const int a = sorder[r];
+        const bool alive = sdead[a] == 0;            // uniform across the wave
+        if (alive) {
+            if (i == a) nms_rank = kept;
+            ++kept;
+            if (cand && rank > r && sdead[i] == 0) {
+                const float xx0 = fmaxf(sx0[a], x0), yy0 = fmaxf(sy0[a], y0);
+                const float xx1 = fminf(sx1[a], x1), yy1 = fminf(sy1[a], y1);
+                const float iw = fmaxf(0.f, xx1 - xx0), ih = fmaxf(0.f, yy1 - yy0);
+                const float inter = iw * ih;
+                const float iou = inter / (sarea[a] + sarea[i] - inter);
+                if (iou > iou_thr) sdead[i] = 1;
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        wm_box_record o;
+        o.box[0] = x0; o.box[1] = y0; o.box[2] = x1; o.box[3] = y1;
+        o.score = score; o.label = label;
+        o.flags = (conf ? WM_FLAG_CONF : 0) | (cand ? WM_FLAG_SCORE : 0) | (nms_rank >= 0 ? WM_FLAG_NMS : 0);
+        o.nms_rank = nms_rank;
+        rec[(size_t)b * NQ + i] = o;
+    }
+}
+
+}  // namespace wm

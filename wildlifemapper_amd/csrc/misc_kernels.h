@@ -1,0 +1,170 @@
+// HBM-bound helper kernels: LayerNorm, patch gather, transposes, converts.
+#pragma once
+#include "wm_common.h"
+
+namespace wm {
+
+// ---------------------------------------------------------------------------
+// LayerNorm over the last dim of [rows, C] fp32, biased variance, two-pass in
+// registers (nn.LayerNorm / LayerNorm2d per pixel: image_encoder.py:173,183,
+// common.py:31-43).  One wave per row, C = 256*NV, 16 B per lane per step.
+// Outputs: fp32 [rows,C] and/or 16-bit [rows,C]; or, if nchw_hw > 0, fp32 in
+// channel-major order out[(row / hw), c, row % hw] (neck output, NHWC -> NCHW).
+// ---------------------------------------------------------------------------
+template <class T, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        float* out32, u16* out16, int64_t rows, int nchw_hw) {
+    constexpr int C = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    f32x4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(sum) * (1.0f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[i][j] - mean;
+            sq += d * d;
+        }
+    const float var = wave_sum(sq) * (1.0f / C);
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c0 = i * 256 + lane * 4;
+        const f32x4 g = *(const f32x4*)(gamma + c0);
+        const f32x4 b = *(const f32x4*)(beta + c0);
+        f32x4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+        if (nchw_hw > 0) {
+            const int64_t img = row / nchw_hw, pix = row % nchw_hw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out32[(img * C + c0 + j) * nchw_hw + pix] = y[j];
+        } else {
+            if (out32) *(f32x4*)(out32 + row * C + c0) = y;
+            if (out16) {
+                typename T::vec4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = T::from_f32(y[j]);
+                *(typename T::vec4*)(out16 + row * C + c0) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Patch gather for the 16x16/s16 embeds (image_encoder.py:409-417, 442-450):
+// x (B,Cin,1024,1024) fp32 -> P [B*4096, Cin*256] 16-bit, column = c*256 + ky*16 + kx
+// (Conv2d weight order).  One thread per 4 consecutive kx.
+// ---------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, u16* __restrict__ out,
+                                                       int B, int Cin) {
+    const int64_t total = (int64_t)B * Cin * 1024 * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x4 = (int)(i & 255);
+        const int y = (int)((i >> 8) & 1023);
+        const int64_t bc = i >> 18;
+        const int c = (int)(bc % Cin);
+        const int64_t b = bc / Cin;
+        const f32x4 v = *(const f32x4*)(x + ((bc * 1024 + y) << 10) + x4 * 4);
+        const int64_t prow = b * 4096 + (y >> 4) * 64 + (x4 >> 2);
+        const int col = c * 256 + (y & 15) * 16 + (x4 & 3) * 4;
+        typename T::vec4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+        *(typename T::vec4*)(out + prow * (Cin * 256) + col) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Batched 2-byte transpose: in [batch][R][C] -> out [batch][C][R], 64x64 LDS tiles.
+// Used for the HFC adaptor's scramble reshape (image_encoder.py:512): per tile the
+// [4096 tok, 1024 ch] buffer re-read as [1024, 4096] must become the K-contiguous
+// A operand [4096, 1024] of proj_back.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose16_kernel(const u16* __restrict__ in, u16* __restrict__ out, int R, int C) {
+    __shared__ u16 tile[64][66];
+    const int64_t boff = (int64_t)blockIdx.z * R * C;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = ty + i * 4;
+        tile[r][tx] = in[boff + (int64_t)(r0 + r) * C + c0 + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = ty + i * 4;
+        out[boff + (int64_t)(c0 + cc) * R + r0 + tx] = tile[tx][cc];
+    }
+}
+
+// fp32 [batch][R][C] -> [batch][C][R] (NCHW <-> NHWC of the 256-channel embedding)
+__global__ __launch_bounds__(256) void transpose32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+    __shared__ float tile[64][65];
+    const int64_t boff = (int64_t)blockIdx.z * R * C;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = ty + i * 4;
+        tile[r][tx] = in[boff + (int64_t)(r0 + r) * C + c0 + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = ty + i * 4;
+        out[boff + (int64_t)(c0 + cc) * R + r0 + tx] = tile[tx][cc];
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void cvt_f32_to_16_kernel(const float* __restrict__ in, u16* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(in + i * 4);
+        typename T::vec4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+        *(typename T::vec4*)(out + i * 4) = o;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void cvt_16_to_f32_kernel(const u16* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const typename T::elem e = __builtin_bit_cast(typename T::elem, in[i]);
+        out[i] = T::to_f32(e);
+    }
+}
+
+// im2col for the neck 3x3 conv (image_encoder.py:113-119): in [B,64,64,C] 16-bit NHWC ->
+// out [B*4096, 9*C], column = tap*C + ci, tap = ky*3+kx, zero outside the grid (padding=1).
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const u16* __restrict__ in, u16* __restrict__ out, int B, int C) {
+    const int chunks = C / 8;                                   // 16-byte chunks per pixel
+    const int64_t total = (int64_t)B * 4096 * 9 * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % chunks);
+        const int tap = (int)((i / chunks) % 9);
+        const int64_t pixg = i / (chunks * 9);
+        const int pix = (int)(pixg & 4095);
+        const int64_t b = pixg >> 12;
+        const int y = (pix >> 6) + tap / 3 - 1, x = (pix & 63) + tap % 3 - 1;
+        s16x8 v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (y >= 0 && y < 64 && x >= 0 && x < 64) v = *(const s16x8*)(in + ((b * 4096 + y * 64 + x) * C) + ch * 8);
+        *(s16x8*)(out + pixg * (9 * C) + tap * C + ch * 8) = v;
+    }
+}
+
+}  // namespace wm

@@ -1,0 +1,983 @@
+// C-ABI + host-side engine of the MI355X WildlifeMapper inference path.
+// See include/wm_hip.h for the contract.  No torch types, no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/wm_hip.h"
+#include "attn16.h"
+#include "dec_kernels.h"
+#include "fft_kernels.h"
+#include "gemm16.h"
+#include "gemm32.h"
+#include "misc_kernels.h"
+#include "wm_common.h"
+
+using namespace wm;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+static int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define WM_TRY(expr)            \
+    do {                        \
+        int _r = (expr);        \
+        if (_r != 0) return _r; \
+    } while (0)
+
+extern "C" const char* wm_last_error(void) { return g_err; }
+extern "C" int wm_abi_version(void) { return WM_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------
+// host-side 16-bit conversion (round to nearest even), used by the weight packer
+// ---------------------------------------------------------------------------
+static inline uint16_t f32_to_bf16_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+static inline uint16_t f32_to_f16_host(float f) {
+    _Float16 h = (_Float16)fminf(fmaxf(f, -65504.f), 65504.f);
+    uint16_t r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int T = 4096;          // tokens per tile (64 x 64)
+constexpr int GRID = 64;
+constexpr int HFC = 1024;        // HFC adaptor width (image_encoder.py:65-87)
+constexpr int HFC_HEADS = 8;
+constexpr int OUTC = 256;        // neck / decoder width
+constexpr int NQ = WM_NUM_QUERIES;
+constexpr int DEC_MLP = 2048;
+
+struct HostW {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct EvPair {
+    hipEvent_t a, b;
+    int kclass;
+    double flops, bytes;
+};
+
+struct Profiler {
+    bool on = false;
+    std::vector<EvPair> used;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    wm_kclass_stat acc[WM_KCLASS_COUNT] = {};
+};
+
+}  // namespace
+
+struct wm_handle {
+    wm_config cfg{};
+    int device = 0;
+    int D = 0, depth = 0, heads = 0, hd = 0, prec = 0, maxB = 0;
+    bool is_global[64] = {};
+    bool finalized = false, enc_ready = false, dec_ready = false;
+    std::map<std::string, std::vector<int64_t>> expected;   // name -> shape
+    std::map<std::string, HostW> staged;
+    std::map<std::string, uint16_t*> w16;
+    std::map<std::string, float*> w32;
+    std::vector<void*> allocs;
+    Profiler prof;
+    int tap_which = -2;
+    float* tap_buf = nullptr;
+
+    // workspace (device)
+    float *resid = nullptr, *tokbase = nullptr;
+    uint16_t *xn16 = nullptr, *ao16 = nullptr, *qkv16 = nullptr, *hid16 = nullptr;
+    uint16_t *p16 = nullptr, *h16 = nullptr, *he16 = nullptr, *hp16 = nullptr, *pt16 = nullptr, *q16 = nullptr,
+             *kv16 = nullptr, *aoh16 = nullptr, *y1n16 = nullptr, *h1_16 = nullptr, *y2_16 = nullptr, *y2t16 = nullptr;
+    float *pt32 = nullptr, *y1 = nullptr, *y1n32 = nullptr, *z32 = nullptr;
+    float *n1 = nullptr, *n2 = nullptr, *emb_nhwc = nullptr, *emb_nchw = nullptr;
+    uint16_t *n1n16 = nullptr, *col16 = nullptr, *x16last = nullptr;
+    float *dkeys = nullptr, *dk_a = nullptr, *dk_b = nullptr, *dk_c = nullptr;      // [B*T,256],[B*T,128] x3
+    float *dq = nullptr, *dt_q = nullptr, *dt_k = nullptr, *dt_v = nullptr, *dt_att = nullptr, *dt_hid = nullptr,
+          *dt_h1 = nullptr, *dt_h2 = nullptr;
+    float *logits = nullptr, *boxes = nullptr, *hfc = nullptr, *tsz_default = nullptr;
+    float2 *fftR = nullptr, *fft_tw = nullptr;
+    float* kpe = nullptr;           // dense PE, token-major [T,256]
+    wm_box_record* records = nullptr;
+};
+
+namespace {
+
+template <class P>
+int dalloc(wm_handle* h, P** out, size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    h->allocs.push_back(p);
+    *out = (P*)p;
+    return 0;
+}
+
+// -------- profiled launch bracket --------
+struct Bracket {
+    wm_handle* h;
+    hipStream_t s;
+    int idx = -1;
+    Bracket(wm_handle* h_, hipStream_t s_, int kclass, double flops, double bytes) : h(h_), s(s_) {
+        if (!h || !h->prof.on) return;
+        Profiler& p = h->prof;
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (!p.pool.empty()) { ev = p.pool.back(); p.pool.pop_back(); }
+        else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
+        hipEventRecord(ev.first, s);
+        p.used.push_back(EvPair{ev.first, ev.second, kclass, flops, bytes});
+        idx = (int)p.used.size() - 1;
+    }
+    ~Bracket() {
+        if (idx >= 0) hipEventRecord(h->prof.used[idx].b, s);
+    }
+};
+
+int prof_collect(wm_handle* h) {
+    Profiler& p = h->prof;
+    for (auto& e : p.used) {
+        HIP_TRY(hipEventSynchronize(e.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+        p.acc[e.kclass].launches += 1;
+        p.acc[e.kclass].ms += ms;
+        p.acc[e.kclass].flops += e.flops;
+        p.acc[e.kclass].bytes += e.bytes;
+        p.pool.push_back({e.a, e.b});
+    }
+    p.used.clear();
+    return 0;
+}
+
+// -------- launchers --------
+template <class T16>
+int launch_gemm16_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm16_kernel<T16>, hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS_BYTES));
+        attr_set = true;
+    }
+    const int grid = (a.M / G16_BM) * (a.N / G16_BN);
+    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
+               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
+    hipLaunchKernelGGL(gemm16_kernel<T16>, dim3(grid), dim3(256), G16_LDS_BYTES, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias,
+                  const float* res, int res_mod, float* out32, void* out16, int M, int N, int K, int act) {
+    if (M <= 0 || N <= 0 || K <= 0 || M % G16_BM || N % G16_BN || K % G16_BK)
+        return fail("gemm16: shape M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, G16_BM, G16_BN, G16_BK);
+    if (!out32 && !out16) return fail("gemm16: no output");
+    Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act};
+    return prec == WM_PREC_FP16 ? launch_gemm16_t<FP16>(h, s, a) : launch_gemm16_t<BF16>(h, s, a);
+}
+
+int launch_gemm32(wm_handle* h, hipStream_t s, const float* A, const float* W, const float* bias, const float* res,
+                  float* out, int M, int N, int K, int act, int lda = 0) {
+    if (K % 16) return fail("gemm32: K=%d must be a multiple of 16", K);
+    Gemm32Args a{A, W, bias, res, out, M, N, K, act, lda > 0 ? lda : K};
+    Bracket br(h, s, WM_KCLASS_OTHER, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    hipLaunchKernelGGL(gemm32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_layernorm(wm_handle* h, hipStream_t s, int prec, const float* x, const float* g, const float* b, float eps,
+                     float* out32, void* out16, int64_t rows, int C, int nchw_hw = 0) {
+    if (C % 256 || C > 1280) return fail("layernorm: C=%d unsupported (multiple of 256, <= 1280)", C);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    Bracket br(h, s, WM_KCLASS_LAYERNORM, 0.0, (double)rows * C * (4.0 + (out32 ? 4.0 : 0.0) + (out16 ? 2.0 : 0.0)));
+#define LN_CASE(NV)                                                                                                   \
+    case NV:                                                                                                          \
+        if (prec == WM_PREC_FP16)                                                                                     \
+            hipLaunchKernelGGL((layernorm_kernel<FP16, NV>), grid, dim3(256), 0, s, x, g, b, eps, out32, (u16*)out16, rows, nchw_hw); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((layernorm_kernel<BF16, NV>), grid, dim3(256), 0, s, x, g, b, eps, out32, (u16*)out16, rows, nchw_hw); \
+        break;
+    switch (C / 256) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5)
+        default: return fail("layernorm: C=%d", C);
+    }
+#undef LN_CASE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <class T16, int HD, bool REL>
+int launch_attn_global_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int batch, int kclass) {
+    using L = GlobalLds<HD, REL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)attn_global_kernel<T16, HD, REL>, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL));
+        attr_set = true;
+    }
+    Bracket br(h, s, kclass, 4.0 * batch * a.heads * (double)a.nq * a.nk * HD, 0.0);
+    hipLaunchKernelGGL((attn_global_kernel<T16, HD, REL>), dim3(a.nq / 128, a.heads, batch), dim3(256), L::TOTAL, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <class T16>
+int launch_attn_global_p(wm_handle* h, hipStream_t s, const AttnArgs& a, int batch, int hd, bool rel, int kclass) {
+    if (a.nq % 128 || a.nk % 64) return fail("attention: nq=%d nk=%d must be multiples of 128/64", a.nq, a.nk);
+    if (rel && (a.nq != T || a.nk != T)) return fail("attention: rel-pos path needs 4096 queries and keys");
+    if (hd == 80 && rel) return launch_attn_global_t<T16, 80, true>(h, s, a, batch, kclass);
+    if (hd == 64 && rel) return launch_attn_global_t<T16, 64, true>(h, s, a, batch, kclass);
+    if (hd == 128 && !rel) return launch_attn_global_t<T16, 128, false>(h, s, a, batch, kclass);
+    if (hd == 64 && !rel) return launch_attn_global_t<T16, 64, false>(h, s, a, batch, kclass);
+    if (hd == 80 && !rel) return launch_attn_global_t<T16, 80, false>(h, s, a, batch, kclass);
+    return fail("attention: head_dim=%d rel=%d not built (64, 80, 128)", hd, (int)rel);
+}
+
+template <class T16, int HD>
+int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int batch) {
+    using L = WindowLds<HD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)attn_window_kernel<T16, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL));
+        attr_set = true;
+    }
+    // useful work only: 4096 real queries x 196 keys
+    Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);
+    hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(25, a.heads, batch), dim3(256), L::TOTAL, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_encoder_attention(wm_handle* h, hipStream_t s, int prec, const void* qkv, const float* qkv_bias,
+                             const float* rel_h, const float* rel_w, void* out, int batch, int heads, int hd, int window) {
+    const int D = heads * hd;
+    AttnArgs a{};
+    a.q = (const u16*)qkv; a.k = (const u16*)qkv + D; a.v = (const u16*)qkv + 2 * D;
+    a.out = (u16*)out;
+    a.q_stride = a.k_stride = a.v_stride = 3 * D;
+    a.out_stride = D;
+    a.nq = a.nk = T;
+    a.scale = 1.0f / sqrtf((float)hd);
+    a.rel_h = rel_h; a.rel_w = rel_w; a.qkv_bias = qkv_bias; a.heads = heads;
+    if (window == 0) {
+        return prec == WM_PREC_FP16 ? launch_attn_global_p<FP16>(h, s, a, batch, hd, true, WM_KCLASS_ATTN_GLOBAL)
+                                    : launch_attn_global_p<BF16>(h, s, a, batch, hd, true, WM_KCLASS_ATTN_GLOBAL);
+    }
+    if (window != 14) return fail("attention: window=%d unsupported (14 or 0)", window);
+    if (hd == 80) return prec == WM_PREC_FP16 ? launch_attn_window_t<FP16, 80>(h, s, a, batch) : launch_attn_window_t<BF16, 80>(h, s, a, batch);
+    if (hd == 64) return prec == WM_PREC_FP16 ? launch_attn_window_t<FP16, 64>(h, s, a, batch) : launch_attn_window_t<BF16, 64>(h, s, a, batch);
+    return fail("attention: head_dim=%d not built for windows (64, 80)", hd);
+}
+
+int launch_mha16(wm_handle* h, hipStream_t s, int prec, const void* q, int qs, const void* k, int ks, const void* v, int vs,
+                 void* out, int os, int batch, int heads, int hd, int nq, int nk) {
+    AttnArgs a{};
+    a.q = (const u16*)q; a.k = (const u16*)k; a.v = (const u16*)v; a.out = (u16*)out;
+    a.q_stride = qs; a.k_stride = ks; a.v_stride = vs; a.out_stride = os;
+    a.nq = nq; a.nk = nk; a.scale = 1.0f / sqrtf((float)hd); a.heads = heads;
+    return prec == WM_PREC_FP16 ? launch_attn_global_p<FP16>(h, s, a, batch, hd, false, WM_KCLASS_ATTN_GLOBAL)
+                                : launch_attn_global_p<BF16>(h, s, a, batch, hd, false, WM_KCLASS_ATTN_GLOBAL);
+}
+
+int launch_mha32(wm_handle* h, hipStream_t s, const float* q, const float* k, const float* v, float* out, int batch,
+                 int heads, int hd, int nq, int nk) {
+    Bracket br(h, s, WM_KCLASS_OTHER, 4.0 * batch * heads * (double)nq * nk * hd, 0.0);
+    if (hd == 16) hipLaunchKernelGGL(mha32_kernel<16>, dim3(nq, heads, batch), dim3(64), 0, s, q, k, v, out, nq, nk, heads);
+    else if (hd == 32) hipLaunchKernelGGL(mha32_kernel<32>, dim3(nq, heads, batch), dim3(64), 0, s, q, k, v, out, nq, nk, heads);
+    else return fail("mha32: head_dim=%d not built (16, 32)", hd);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <class K, class... Args>
+int launch_simple(wm_handle* h, hipStream_t s, double bytes, K kern, dim3 grid, dim3 block, Args... args) {
+    Bracket br(h, s, WM_KCLASS_OTHER, 0.0, bytes);
+    hipLaunchKernelGGL(kern, grid, block, 0, s, args...);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+unsigned grid_for(int64_t n, int per = 256, unsigned cap = 256 * 16) {
+    int64_t g = (n + per - 1) / per;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// -------- expected weights --------
+void add_attn(std::map<std::string, std::vector<int64_t>>& m, const std::string& p, int E, int internal) {
+    for (const char* n : {"q_proj", "k_proj", "v_proj"}) {
+        m[p + n + ".weight"] = {internal, E};
+        m[p + n + ".bias"] = {internal};
+    }
+    m[p + "out_proj.weight"] = {E, internal};
+    m[p + "out_proj.bias"] = {E};
+}
+
+void build_expected(wm_handle* h) {
+    auto& m = h->expected;
+    const int D = h->D, hd = h->hd;
+    const std::string e = "image_encoder.";
+    m[e + "pos_embed"] = {1, GRID, GRID, D};
+    m[e + "patch_embed.proj.weight"] = {D, 3, 16, 16};
+    m[e + "patch_embed.proj.bias"] = {D};
+    m[e + "hfc_embed.proj.weight"] = {HFC, 1, 16, 16};
+    m[e + "hfc_embed.proj.bias"] = {HFC};
+    const std::string a = e + "hfc_attn.";
+    m[a + "pos_embed"] = {1, HFC, GRID, GRID};
+    m[a + "proj_hfc.weight"] = {HFC, HFC, 1, 1};
+    m[a + "proj_hfc.bias"] = {HFC};
+    m[a + "proj_patch.weight"] = {HFC, D, 1, 1};
+    m[a + "proj_patch.bias"] = {HFC};
+    m[a + "cross_attn.in_proj_weight"] = {3 * HFC, HFC};
+    m[a + "cross_attn.in_proj_bias"] = {3 * HFC};
+    m[a + "cross_attn.out_proj.weight"] = {HFC, HFC};
+    m[a + "cross_attn.out_proj.bias"] = {HFC};
+    for (const char* n : {"linear1", "linear2"}) {
+        m[a + n + ".weight"] = {HFC, HFC};
+        m[a + n + ".bias"] = {HFC};
+    }
+    for (const char* n : {"norm1", "norm2"}) {
+        m[a + n + ".weight"] = {HFC};
+        m[a + n + ".bias"] = {HFC};
+    }
+    m[a + "proj_back.weight"] = {D, HFC, 1, 1};
+    m[a + "proj_back.bias"] = {D};
+    for (int i = 0; i < h->depth; ++i) {
+        const std::string b = e + "blocks." + std::to_string(i) + ".";
+        const int size = h->is_global[i] ? GRID : 14;
+        m[b + "norm1.weight"] = {D};
+        m[b + "norm1.bias"] = {D};
+        m[b + "attn.rel_pos_h"] = {2 * size - 1, hd};
+        m[b + "attn.rel_pos_w"] = {2 * size - 1, hd};
+        m[b + "attn.qkv.weight"] = {3 * D, D};
+        m[b + "attn.qkv.bias"] = {3 * D};
+        m[b + "attn.proj.weight"] = {D, D};
+        m[b + "attn.proj.bias"] = {D};
+        m[b + "norm2.weight"] = {D};
+        m[b + "norm2.bias"] = {D};
+        m[b + "mlp.lin1.weight"] = {4 * D, D};
+        m[b + "mlp.lin1.bias"] = {4 * D};
+        m[b + "mlp.lin2.weight"] = {D, 4 * D};
+        m[b + "mlp.lin2.bias"] = {D};
+    }
+    m[e + "neck.0.weight"] = {OUTC, D, 1, 1};
+    m[e + "neck.1.weight"] = {OUTC};
+    m[e + "neck.1.bias"] = {OUTC};
+    m[e + "neck.2.weight"] = {OUTC, OUTC, 3, 3};
+    m[e + "neck.3.weight"] = {OUTC};
+    m[e + "neck.3.bias"] = {OUTC};
+    m["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"] = {2, OUTC / 2};
+    const std::string d = "mask_decoder.";
+    for (int i = 0; i < 2; ++i) {
+        const std::string L = d + "transformer.layers." + std::to_string(i) + ".";
+        add_attn(m, L + "self_attn.", OUTC, OUTC);
+        add_attn(m, L + "cross_attn_token_to_image.", OUTC, OUTC / 2);
+        add_attn(m, L + "cross_attn_image_to_token.", OUTC, OUTC / 2);
+        for (const char* n : {"norm1", "norm2", "norm3", "norm4"}) {
+            m[L + n + ".weight"] = {OUTC};
+            m[L + n + ".bias"] = {OUTC};
+        }
+        m[L + "mlp.lin1.weight"] = {DEC_MLP, OUTC};
+        m[L + "mlp.lin1.bias"] = {DEC_MLP};
+        m[L + "mlp.lin2.weight"] = {OUTC, DEC_MLP};
+        m[L + "mlp.lin2.bias"] = {OUTC};
+    }
+    add_attn(m, d + "transformer.final_attn_token_to_image.", OUTC, OUTC / 2);
+    m[d + "transformer.norm_final_attn.weight"] = {OUTC};
+    m[d + "transformer.norm_final_attn.bias"] = {OUTC};
+    m[d + "iou_token.weight"] = {1, OUTC};                 // parameter exists, unused in forward (box_decoder.py:52)
+    m[d + "mask_tokens.weight"] = {NQ, OUTC};
+    const int cls_dims[4] = {OUTC, OUTC, OUTC, WM_NUM_LOGITS}, box_dims[4] = {OUTC, OUTC, OUTC, 4};
+    for (int j = 0; j < 3; ++j) {
+        m[d + "class_embed.layers." + std::to_string(j) + ".weight"] = {cls_dims[j + 1], cls_dims[j]};
+        m[d + "class_embed.layers." + std::to_string(j) + ".bias"] = {cls_dims[j + 1]};
+        m[d + "bbox_embed.layers." + std::to_string(j) + ".weight"] = {box_dims[j + 1], box_dims[j]};
+        m[d + "bbox_embed.layers." + std::to_string(j) + ".bias"] = {box_dims[j + 1]};
+    }
+}
+
+int upload16(wm_handle* h, const std::string& key, const float* src, size_t n) {
+    std::vector<uint16_t> tmp(n);
+    if (h->prec == WM_PREC_FP16) for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_f16_host(src[i]);
+    else for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16_host(src[i]);
+    uint16_t* d = nullptr;
+    WM_TRY(dalloc(h, &d, n * 2));
+    HIP_TRY(hipMemcpy(d, tmp.data(), n * 2, hipMemcpyHostToDevice));
+    h->w16[key] = d;
+    return 0;
+}
+
+int upload32(wm_handle* h, const std::string& key, const float* src, size_t n) {
+    float* d = nullptr;
+    WM_TRY(dalloc(h, &d, n * 4));
+    HIP_TRY(hipMemcpy(d, src, n * 4, hipMemcpyHostToDevice));
+    h->w32[key] = d;
+    return 0;
+}
+
+bool ends_with(const std::string& s, const char* suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------
+extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
+    if (!cfg || !out) return fail("wm_create: null argument");
+    if (cfg->embed_dim <= 0 || cfg->num_heads <= 0 || cfg->embed_dim % cfg->num_heads) return fail("wm_create: bad dims");
+    if (cfg->depth <= 0 || cfg->depth > 64) return fail("wm_create: depth %d out of range", cfg->depth);
+    if (cfg->max_batch <= 0) return fail("wm_create: max_batch must be positive");
+    if (cfg->embed_dim % 256 || cfg->embed_dim > 1280) return fail("wm_create: embed_dim %d unsupported (multiple of 256, <= 1280)", cfg->embed_dim);
+    const int hd = cfg->embed_dim / cfg->num_heads;
+    if (hd != 64 && hd != 80) return fail("wm_create: head_dim %d unsupported (64 or 80)", hd);
+    if (cfg->precision != WM_PREC_BF16 && cfg->precision != WM_PREC_FP16) return fail("wm_create: bad precision");
+    if (cfg->num_global < 0 || cfg->num_global > WM_MAX_GLOBAL) return fail("wm_create: bad num_global");
+    HIP_TRY(hipSetDevice(device));
+    wm_handle* h = new wm_handle();
+    h->cfg = *cfg; h->device = device;
+    h->D = cfg->embed_dim; h->depth = cfg->depth; h->heads = cfg->num_heads; h->hd = hd;
+    h->prec = cfg->precision; h->maxB = cfg->max_batch;
+    for (int i = 0; i < cfg->num_global; ++i) {
+        const int g = cfg->global_attn_indexes[i];
+        if (g < 0 || g >= cfg->depth) { delete h; return fail("wm_create: global index %d out of range", g); }
+        h->is_global[g] = true;
+    }
+    build_expected(h);
+
+    const size_t B = (size_t)h->maxB, D = (size_t)h->D, BT = B * T;
+    int r = 0;
+#define A(ptr, bytes) if (!r) r = dalloc(h, &h->ptr, (bytes))
+    A(resid, BT * D * 4); A(tokbase, BT * D * 4);
+    A(xn16, BT * D * 2); A(ao16, BT * D * 2); A(qkv16, BT * 3 * D * 2); A(hid16, BT * 4 * D * 2);
+    A(p16, BT * 768 * 2); A(h16, BT * 256 * 2); A(he16, BT * HFC * 2); A(hp16, BT * HFC * 2); A(pt16, BT * HFC * 2);
+    A(q16, BT * HFC * 2); A(kv16, BT * 2 * HFC * 2); A(aoh16, BT * HFC * 2); A(y1n16, BT * HFC * 2); A(h1_16, BT * HFC * 2);
+    A(y2_16, BT * HFC * 2); A(y2t16, BT * HFC * 2);
+    A(pt32, BT * HFC * 4); A(y1, BT * HFC * 4); A(y1n32, BT * HFC * 4); A(z32, BT * HFC * 4);
+    A(n1, BT * OUTC * 4); A(n2, BT * OUTC * 4); A(emb_nhwc, BT * OUTC * 4); A(emb_nchw, BT * OUTC * 4);
+    A(n1n16, BT * OUTC * 2); A(col16, BT * 9 * OUTC * 2); A(x16last, BT * D * 2);
+    A(dkeys, BT * OUTC * 4); A(dk_a, BT * 128 * 4); A(dk_b, BT * 128 * 4); A(dk_c, BT * 128 * 4);
+    A(dq, B * NQ * OUTC * 4); A(dt_q, B * NQ * OUTC * 4); A(dt_k, B * NQ * OUTC * 4); A(dt_v, B * NQ * OUTC * 4);
+    A(dt_att, B * NQ * OUTC * 4); A(dt_hid, B * NQ * DEC_MLP * 4); A(dt_h1, B * NQ * OUTC * 4); A(dt_h2, B * NQ * OUTC * 4);
+    A(logits, B * NQ * WM_NUM_LOGITS * 4); A(boxes, B * NQ * 4 * 4);
+    A(hfc, B * 1024 * 1024 * 4); A(tsz_default, B * 2 * 4);
+    A(fftR, B * FFT_N * FFT_L * sizeof(float2)); A(fft_tw, FFT_N * sizeof(float2));
+    A(kpe, (size_t)T * OUTC * 4);
+    A(records, B * NQ * sizeof(wm_box_record));
+#undef A
+    if (r) { wm_destroy(h); return r; }
+    // FFT twiddles exp(-2 pi i k / 1024), computed in double
+    {
+        std::vector<float2> tw(FFT_N);
+        for (int k = 0; k < FFT_N; ++k) {
+            const double ang = -2.0 * M_PI * k / FFT_N;
+            tw[k] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+        hipError_t e = hipMemcpy(h->fft_tw, tw.data(), FFT_N * sizeof(float2), hipMemcpyHostToDevice);
+        std::vector<float> ts(B * 2, 1024.f);
+        if (e == hipSuccess) e = hipMemcpy(h->tsz_default, ts.data(), B * 2 * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { wm_destroy(h); return fail("wm_create: twiddle upload failed: %s", hipGetErrorString(e)); }
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int wm_destroy(wm_handle* h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (void* p : h->allocs) if (p) hipFree(p);
+    if (h->tap_buf) hipFree(h->tap_buf);
+    for (auto& e : h->prof.used) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto& e : h->prof.pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete h;
+    return 0;
+}
+
+extern "C" int wm_load_weight(wm_handle* h, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+    if (!h || !name || !host_data || !shape) return fail("wm_load_weight: null argument");
+    auto it = h->expected.find(name);
+    if (it == h->expected.end()) return fail("wm_load_weight: unknown tensor '%s'", name);
+    const auto& es = it->second;
+    bool ok = (int)es.size() == ndim;
+    size_t n = 1;
+    for (int i = 0; ok && i < ndim; ++i) { ok = es[i] == shape[i]; n *= (size_t)shape[i]; }
+    if (!ok) return fail("wm_load_weight: shape mismatch for '%s'", name);
+    HostW w;
+    w.shape.assign(shape, shape + ndim);
+    w.data.assign(host_data, host_data + n);
+    h->staged[name] = std::move(w);
+    h->finalized = false;
+    return 0;
+}
+
+extern "C" int wm_finalize_weights(wm_handle* h) {
+    if (!h) return fail("wm_finalize_weights: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    // Two independently loadable groups: the encoder ("image_encoder.*") and the
+    // decoder ("mask_decoder.*" + "prompt_encoder.*").  A group is ready when every
+    // tensor of it has been loaded; a partially loaded group is an error.
+    for (int grp = 0; grp < 2; ++grp) {
+        std::string missing;
+        int nmiss = 0, nhave = 0;
+        for (auto& kv : h->expected) {
+            const bool enc = kv.first.rfind("image_encoder.", 0) == 0;
+            if ((grp == 0) != enc) continue;
+            if (h->staged.count(kv.first) || h->w16.count(kv.first) || h->w32.count(kv.first)) { ++nhave; continue; }
+            if (nmiss < 4) missing += (nmiss ? ", " : "") + kv.first;
+            ++nmiss;
+        }
+        if (nmiss && nhave)
+            return fail("wm_finalize_weights: %s group incomplete, %d tensors missing (%s%s)", grp == 0 ? "encoder" : "decoder",
+                        nmiss, missing.c_str(), nmiss > 4 ? ", ..." : "");
+        if (grp == 0) h->enc_ready = nmiss == 0;
+        else h->dec_ready = nmiss == 0;
+    }
+    if (!h->enc_ready && !h->dec_ready) return fail("wm_finalize_weights: no weights loaded");
+    // re-upload: free previous device copies of the tensors being replaced
+    for (auto& kv : h->staged) {
+        auto i16 = h->w16.find(kv.first);
+        if (i16 != h->w16.end()) { hipFree(i16->second); for (auto& a : h->allocs) if (a == i16->second) a = nullptr; h->w16.erase(i16); }
+        auto i32 = h->w32.find(kv.first);
+        if (i32 != h->w32.end()) { hipFree(i32->second); for (auto& a : h->allocs) if (a == i32->second) a = nullptr; h->w32.erase(i32); }
+    }
+    const int D = h->D;
+    for (auto& kv : h->staged) {
+        const std::string& name = kv.first;
+        const HostW& w = kv.second;
+        const size_t n = w.data.size();
+        const bool enc = name.rfind("image_encoder.", 0) == 0;
+        const bool is_gemm_w = enc && (ends_with(name, ".weight") || ends_with(name, "in_proj_weight")) && w.shape.size() >= 2;
+        if (name == "image_encoder.neck.2.weight") {
+            // [co][ci][ky][kx] -> [co][tap][ci]
+            std::vector<float> t(n);
+            for (int co = 0; co < OUTC; ++co)
+                for (int ci = 0; ci < OUTC; ++ci)
+                    for (int tap = 0; tap < 9; ++tap)
+                        t[((size_t)co * 9 + tap) * OUTC + ci] = w.data[((size_t)co * OUTC + ci) * 9 + tap];
+            WM_TRY(upload16(h, name, t.data(), n));
+        } else if (name == "image_encoder.hfc_attn.pos_embed") {
+            // NCHW (1,1024,64,64) -> token-major [4096,1024] (added after proj_hfc, image_encoder.py:494)
+            std::vector<float> t(n);
+            for (int c = 0; c < HFC; ++c)
+                for (int p = 0; p < T; ++p) t[(size_t)p * HFC + c] = w.data[(size_t)c * T + p];
+            WM_TRY(upload32(h, name, t.data(), n));
+        } else if (is_gemm_w) {
+            WM_TRY(upload16(h, name, w.data.data(), n));
+        } else {
+            WM_TRY(upload32(h, name, w.data.data(), n));
+        }
+    }
+    // dense positional encoding, token-major (pos_encoder.py:50-70)
+    if (h->staged.count("prompt_encoder.pe_layer.positional_encoding_gaussian_matrix")) {
+        const HostW& g = h->staged["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"];
+        const int F = OUTC / 2;
+        std::vector<float> pe((size_t)T * OUTC);
+        for (int y = 0; y < GRID; ++y)
+            for (int x = 0; x < GRID; ++x) {
+                const float cx = 2.0f * ((x + 0.5f) / GRID) - 1.0f, cy = 2.0f * ((y + 0.5f) / GRID) - 1.0f;
+                for (int f = 0; f < F; ++f) {
+                    float arg = cx * g.data[f] + cy * g.data[F + f];
+                    arg = arg * 6.283185307179586f;
+                    pe[(size_t)(y * GRID + x) * OUTC + f] = (float)sin((double)arg);
+                    pe[(size_t)(y * GRID + x) * OUTC + F + f] = (float)cos((double)arg);
+                }
+            }
+        HIP_TRY(hipMemcpy(h->kpe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
+    }
+    (void)D;
+    h->staged.clear();
+    h->finalized = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// the path
+// ---------------------------------------------------------------------------
+namespace {
+
+int check_ready(wm_handle* h, int batch, const char* fn, bool need_enc, bool need_dec) {
+    if (!h) return fail("%s: null handle", fn);
+    if (!h->finalized) return fail("%s: weights not finalized", fn);
+    if (need_enc && !h->enc_ready) return fail("%s: encoder weights not loaded", fn);
+    if (need_dec && !h->dec_ready) return fail("%s: decoder weights not loaded", fn);
+    if (batch <= 0 || batch > h->maxB) return fail("%s: batch %d outside 1..%d", fn, batch, h->maxB);
+    HIP_TRY(hipSetDevice(h->device));
+    return 0;
+}
+
+const uint16_t* W16(wm_handle* h, const std::string& n) { return h->w16.at(n); }
+const float* W32(wm_handle* h, const std::string& n) { return h->w32.at(n); }
+
+int do_tap(wm_handle* h, hipStream_t s, int which, int batch) {
+    if (h->tap_which != which) return 0;
+    if (!h->tap_buf) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, (size_t)h->maxB * T * h->D * 4));
+        h->tap_buf = (float*)p;
+    }
+    HIP_TRY(hipMemcpyAsync(h->tap_buf, h->resid, (size_t)batch * T * h->D * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int fft_impl(wm_handle* h, const float* x, float* out, int B, hipStream_t s) {
+    WM_TRY(launch_simple(h, s, (double)B * (12e6 + 3e6), fft_rows_fwd_kernel, dim3(FFT_N, B), dim3(256), x, h->fftR, (const float2*)h->fft_tw));
+    WM_TRY(launch_simple(h, s, (double)B * 6e6, fft_cols_kernel, dim3(FFT_L, B), dim3(256), h->fftR, (const float2*)h->fft_tw));
+    WM_TRY(launch_simple(h, s, (double)B * (12e6 + 3e6 + 4e6), fft_rows_inv_kernel, dim3(FFT_N, B), dim3(256), x, (const float2*)h->fftR,
+                         (const float2*)h->fft_tw, out));
+    return 0;
+}
+
+int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw, int B, hipStream_t s) {
+    const int D = h->D, P = h->prec, M = B * T;
+    const std::string e = "image_encoder.", a = e + "hfc_attn.";
+    // ---- stem: patch / HFC embeds (image_encoder.py:124-128) ----
+    if (P == WM_PREC_FP16) {
+        WM_TRY(launch_simple(h, s, B * 18.9e6, patchify_kernel<FP16>, dim3(grid_for((int64_t)B * 3 * 1024 * 256)), dim3(256), x, (u16*)h->p16, B, 3));
+        WM_TRY(launch_simple(h, s, B * 6.3e6, patchify_kernel<FP16>, dim3(grid_for((int64_t)B * 1024 * 256)), dim3(256), hfc, (u16*)h->h16, B, 1));
+    } else {
+        WM_TRY(launch_simple(h, s, B * 18.9e6, patchify_kernel<BF16>, dim3(grid_for((int64_t)B * 3 * 1024 * 256)), dim3(256), x, (u16*)h->p16, B, 3));
+        WM_TRY(launch_simple(h, s, B * 6.3e6, patchify_kernel<BF16>, dim3(grid_for((int64_t)B * 1024 * 256)), dim3(256), hfc, (u16*)h->h16, B, 1));
+    }
+    // t = patch_embed(x) + pos_embed  -> tokbase (fp32) and xn16 (16-bit copy for proj_patch)
+    WM_TRY(launch_gemm16(h, s, P, h->p16, W16(h, e + "patch_embed.proj.weight"), W32(h, e + "patch_embed.proj.bias"),
+                         W32(h, e + "pos_embed"), T, h->tokbase, h->xn16, M, D, 768, ACT_NONE));
+    WM_TRY(launch_gemm16(h, s, P, h->h16, W16(h, e + "hfc_embed.proj.weight"), W32(h, e + "hfc_embed.proj.bias"),
+                         nullptr, 0, nullptr, h->he16, M, HFC, 256, ACT_NONE));
+    // ---- HFC adaptor (image_encoder.py:486-516) ----
+    WM_TRY(launch_gemm16(h, s, P, h->he16, W16(h, a + "proj_hfc.weight"), W32(h, a + "proj_hfc.bias"),
+                         W32(h, a + "pos_embed"), T, nullptr, h->hp16, M, HFC, HFC, ACT_NONE));                    // :494
+    WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, a + "proj_patch.weight"), W32(h, a + "proj_patch.bias"),
+                         nullptr, 0, h->pt32, h->pt16, M, HFC, D, ACT_NONE));                                       // :495
+    const uint16_t* wi = W16(h, a + "cross_attn.in_proj_weight");
+    const float* bi = W32(h, a + "cross_attn.in_proj_bias");
+    WM_TRY(launch_gemm16(h, s, P, h->pt16, wi, bi, nullptr, 0, nullptr, h->q16, M, HFC, HFC, ACT_NONE));
+    WM_TRY(launch_gemm16(h, s, P, h->hp16, wi + (size_t)HFC * HFC, bi + HFC, nullptr, 0, nullptr, h->kv16, M, 2 * HFC, HFC, ACT_NONE));
+    WM_TRY(launch_mha16(h, s, P, h->q16, HFC, h->kv16, 2 * HFC, h->kv16 + HFC, 2 * HFC, h->aoh16, HFC, B, HFC_HEADS,
+                        HFC / HFC_HEADS, T, T));                                                                      // :500-503
+    WM_TRY(launch_gemm16(h, s, P, h->aoh16, W16(h, a + "cross_attn.out_proj.weight"), W32(h, a + "cross_attn.out_proj.bias"),
+                         h->pt32, 0, h->y1, nullptr, M, HFC, HFC, ACT_NONE));                                       // + residual :504
+    WM_TRY(launch_layernorm(h, s, P, h->y1, W32(h, a + "norm1.weight"), W32(h, a + "norm1.bias"), 1e-5f, h->y1n32, h->y1n16, M, HFC));
+    WM_TRY(launch_gemm16(h, s, P, h->y1n16, W16(h, a + "linear1.weight"), W32(h, a + "linear1.bias"), nullptr, 0, nullptr,
+                         h->h1_16, M, HFC, HFC, ACT_RELU));
+    WM_TRY(launch_gemm16(h, s, P, h->h1_16, W16(h, a + "linear2.weight"), W32(h, a + "linear2.bias"), h->y1n32, 0, h->z32,
+                         nullptr, M, HFC, HFC, ACT_NONE));                                                          // :506-508
+    WM_TRY(launch_layernorm(h, s, P, h->z32, W32(h, a + "norm2.weight"), W32(h, a + "norm2.bias"), 1e-5f, nullptr, h->y2_16, M, HFC));
+    // scramble (:512): per tile [4096 tok,1024 ch] re-read as [1024, 4096]; make it the K-contiguous A operand
+    WM_TRY(launch_simple(h, s, B * 16.8e6, transpose16_kernel, dim3(T / 64, HFC / 64, B), dim3(256), (const u16*)h->y2_16, (u16*)h->y2t16, HFC, T));
+    // x = proj_back(scrambled) + t   (:513-514, :131)
+    WM_TRY(launch_gemm16(h, s, P, h->y2t16, W16(h, a + "proj_back.weight"), W32(h, a + "proj_back.bias"), h->tokbase, 0,
+                         h->resid, nullptr, M, D, HFC, ACT_NONE));
+    WM_TRY(do_tap(h, s, -1, B));
+
+    // ---- transformer blocks (image_encoder.py:188-204) ----
+    for (int i = 0; i < h->depth; ++i) {
+        const std::string b = e + "blocks." + std::to_string(i) + ".";
+        WM_TRY(launch_layernorm(h, s, P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, nullptr, h->xn16, M, D));
+        WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "attn.qkv.weight"), W32(h, b + "attn.qkv.bias"), nullptr, 0, nullptr,
+                             h->qkv16, M, 3 * D, D, ACT_NONE));
+        WM_TRY(launch_encoder_attention(h, s, P, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
+                                        W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14));
+        WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
+                             h->resid, nullptr, M, D, D, ACT_NONE));
+        WM_TRY(launch_layernorm(h, s, P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, nullptr, h->xn16, M, D));
+        WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.bias"), nullptr, 0, nullptr,
+                             h->hid16, M, 4 * D, D, ACT_GELU));
+        const bool last = i == h->depth - 1;
+        WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
+                             h->resid, last ? h->x16last : nullptr, M, D, 4 * D, ACT_NONE));
+        WM_TRY(do_tap(h, s, i, B));
+    }
+
+    // ---- neck (image_encoder.py:105-121,136) ----
+    WM_TRY(launch_gemm16(h, s, P, h->x16last, W16(h, e + "neck.0.weight"), nullptr, nullptr, 0, h->n1, nullptr, M, OUTC, D, ACT_NONE));
+    WM_TRY(launch_layernorm(h, s, P, h->n1, W32(h, e + "neck.1.weight"), W32(h, e + "neck.1.bias"), 1e-6f, nullptr, h->n1n16, M, OUTC));
+    WM_TRY(launch_simple(h, s, B * 21e6, im2col3x3_kernel, dim3(grid_for((int64_t)M * 9 * (OUTC / 8))), dim3(256), (const u16*)h->n1n16,
+                         (u16*)h->col16, B, OUTC));
+    WM_TRY(launch_gemm16(h, s, P, h->col16, W16(h, e + "neck.2.weight"), nullptr, nullptr, 0, h->n2, nullptr, M, OUTC, 9 * OUTC, ACT_NONE));
+    WM_TRY(launch_layernorm(h, s, P, h->n2, W32(h, e + "neck.3.weight"), W32(h, e + "neck.3.bias"), 1e-6f, h->emb_nhwc, nullptr, M, OUTC));
+    if (out_nchw)
+        WM_TRY(launch_simple(h, s, B * 8.4e6, transpose32_kernel, dim3(OUTC / 64, T / 64, B), dim3(256), (const float*)h->emb_nhwc, out_nchw, T, OUTC));
+    return 0;
+}
+
+// attention block of the decoder (transformer.py:217-240) on fp32 buffers
+struct DecAttnW { const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo; int internal; };
+
+DecAttnW dec_w(wm_handle* h, const std::string& p, int internal) {
+    return DecAttnW{W32(h, p + "q_proj.weight"), W32(h, p + "q_proj.bias"), W32(h, p + "k_proj.weight"), W32(h, p + "k_proj.bias"),
+                    W32(h, p + "v_proj.weight"), W32(h, p + "v_proj.bias"), W32(h, p + "out_proj.weight"), W32(h, p + "out_proj.bias"), internal};
+}
+
+}  // namespace
+
+// elementwise fp32 add with a row-broadcast second operand: out[r,c] = a[r,c] + b[r % mod, c]
+__global__ __launch_bounds__(256) void add_bcast_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                        int64_t rows, int C, int mod) {
+    const int64_t n4 = rows * C / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = (i * 4) / C;
+        const int c = (int)((i * 4) % C);
+        const f32x4 x = *(const f32x4*)(a + i * 4);
+        const f32x4 y = *(const f32x4*)(b + (r % mod) * C + c);
+        *(f32x4*)(out + i * 4) = x + y;
+    }
+}
+
+namespace {
+
+int decoder_impl(wm_handle* h, const float* keys_nhwc, float* logits, float* boxes, int B, hipStream_t s) {
+    const std::string t = "mask_decoder.transformer.";
+    const int E = OUTC, Mk = B * T, Mq = B * NQ;
+    const float* tok = W32(h, "mask_decoder.mask_tokens.weight");      // [51,256] = tokens and query PE (box_decoder.py:128-131)
+    float* keys = h->dkeys;
+    HIP_TRY(hipMemcpyAsync(keys, keys_nhwc, (size_t)Mk * E * 4, hipMemcpyDeviceToDevice, s));
+    float* queries = h->dq;
+    for (int b = 0; b < B; ++b)
+        HIP_TRY(hipMemcpyAsync(queries + (size_t)b * NQ * E, tok, (size_t)NQ * E * 4, hipMemcpyDeviceToDevice, s));
+
+    auto add_q = [&](float* out) {   // queries + query_pe
+        return launch_simple(h, s, 0.0, add_bcast_kernel, dim3(grid_for((int64_t)Mq * E / 4)), dim3(256), (const float*)queries, tok, out, (int64_t)Mq, E, NQ);
+    };
+    auto add_k = [&](float* out) {   // keys + key_pe
+        return launch_simple(h, s, 0.0, add_bcast_kernel, dim3(grid_for((int64_t)Mk * E / 4)), dim3(256), (const float*)keys, (const float*)h->kpe, out, (int64_t)Mk, E, T);
+    };
+    auto ln = [&](float* x, const std::string& n, int rows) {
+        return launch_layernorm(h, s, h->prec, x, W32(h, n + ".weight"), W32(h, n + ".bias"), 1e-5f, x, nullptr, rows, E);
+    };
+    // token -> image attention: q from (queries+pe), k from (keys+pe) [kin], v from keys; result added to queries
+    auto token_to_image = [&](const DecAttnW& w, const float* kin) -> int {
+        WM_TRY(add_q(h->dt_h1));
+        WM_TRY(launch_gemm32(h, s, h->dt_h1, w.wq, w.bq, nullptr, h->dt_q, Mq, w.internal, E, ACT_NONE));
+        WM_TRY(launch_gemm32(h, s, kin, w.wk, w.bk, nullptr, h->dk_a, Mk, w.internal, E, ACT_NONE));
+        WM_TRY(launch_gemm32(h, s, keys, w.wv, w.bv, nullptr, h->dk_b, Mk, w.internal, E, ACT_NONE));
+        WM_TRY(launch_mha32(h, s, h->dt_q, h->dk_a, h->dk_b, h->dt_att, B, 8, w.internal / 8, NQ, T));
+        WM_TRY(launch_gemm32(h, s, h->dt_att, w.wo, w.bo, queries, queries, Mq, E, w.internal, ACT_NONE));
+        return 0;
+    };
+    float* kpe_sum = h->n1;   // reuse [B*T,256] fp32 scratch of the neck: keys + key_pe
+
+    for (int i = 0; i < 2; ++i) {
+        const std::string L = t + "layers." + std::to_string(i) + ".";
+        // (1) self attention of the tokens (transformer.py:151-158)
+        {
+            const DecAttnW w = dec_w(h, L + "self_attn.", E);
+            const float* qin = queries;
+            if (i != 0) { WM_TRY(add_q(h->dt_h1)); qin = h->dt_h1; }
+            WM_TRY(launch_gemm32(h, s, qin, w.wq, w.bq, nullptr, h->dt_q, Mq, E, E, ACT_NONE));
+            WM_TRY(launch_gemm32(h, s, qin, w.wk, w.bk, nullptr, h->dt_k, Mq, E, E, ACT_NONE));
+            WM_TRY(launch_gemm32(h, s, queries, w.wv, w.bv, nullptr, h->dt_v, Mq, E, E, ACT_NONE));
+            WM_TRY(launch_mha32(h, s, h->dt_q, h->dt_k, h->dt_v, h->dt_att, B, 8, E / 8, NQ, NQ));
+            // layer 0 replaces the queries (no residual, :155-156); later layers add
+            WM_TRY(launch_gemm32(h, s, h->dt_att, w.wo, w.bo, i == 0 ? nullptr : queries, queries, Mq, E, E, ACT_NONE));
+            WM_TRY(ln(queries, L + "norm1", Mq));
+        }
+        // (2) tokens attend to the image (:160-165)
+        WM_TRY(add_k(kpe_sum));
+        WM_TRY(token_to_image(dec_w(h, L + "cross_attn_token_to_image.", E / 2), kpe_sum));
+        WM_TRY(ln(queries, L + "norm2", Mq));
+        // (3) MLP (:167-170)
+        WM_TRY(launch_gemm32(h, s, queries, W32(h, L + "mlp.lin1.weight"), W32(h, L + "mlp.lin1.bias"), nullptr, h->dt_hid, Mq, DEC_MLP, E, ACT_RELU));
+        WM_TRY(launch_gemm32(h, s, h->dt_hid, W32(h, L + "mlp.lin2.weight"), W32(h, L + "mlp.lin2.bias"), queries, queries, Mq, E, DEC_MLP, ACT_NONE));
+        WM_TRY(ln(queries, L + "norm3", Mq));
+        // (4) image attends to the tokens (:172-178): q = keys+pe, k = queries+pe, v = queries
+        {
+            const DecAttnW w = dec_w(h, L + "cross_attn_image_to_token.", E / 2);
+            WM_TRY(add_q(h->dt_h1));
+            WM_TRY(launch_gemm32(h, s, kpe_sum, w.wq, w.bq, nullptr, h->dk_a, Mk, w.internal, E, ACT_NONE));
+            WM_TRY(launch_gemm32(h, s, h->dt_h1, w.wk, w.bk, nullptr, h->dt_k, Mq, w.internal, E, ACT_NONE));
+            WM_TRY(launch_gemm32(h, s, queries, w.wv, w.bv, nullptr, h->dt_v, Mq, w.internal, E, ACT_NONE));
+            WM_TRY(launch_mha32(h, s, h->dk_a, h->dt_k, h->dt_v, h->dk_c, B, 8, w.internal / 8, T, NQ));
+            WM_TRY(launch_gemm32(h, s, h->dk_c, w.wo, w.bo, keys, keys, Mk, E, w.internal, ACT_NONE));
+            WM_TRY(ln(keys, L + "norm4", Mk));
+        }
+    }
+    // final token -> image attention (transformer.py:100-104)
+    WM_TRY(add_k(kpe_sum));
+    WM_TRY(token_to_image(dec_w(h, t + "final_attn_token_to_image.", E / 2), kpe_sum));
+    WM_TRY(ln(queries, t + "norm_final_attn", Mq));
+
+    // heads (box_decoder.py:102-103)
+    const std::string c = "mask_decoder.class_embed.layers.", bb = "mask_decoder.bbox_embed.layers.";
+    WM_TRY(launch_gemm32(h, s, queries, W32(h, c + "0.weight"), W32(h, c + "0.bias"), nullptr, h->dt_h1, Mq, E, E, ACT_RELU));
+    WM_TRY(launch_gemm32(h, s, h->dt_h1, W32(h, c + "1.weight"), W32(h, c + "1.bias"), nullptr, h->dt_h2, Mq, E, E, ACT_RELU));
+    WM_TRY(launch_gemm32(h, s, h->dt_h2, W32(h, c + "2.weight"), W32(h, c + "2.bias"), nullptr, logits, Mq, WM_NUM_LOGITS, E, ACT_NONE));
+    WM_TRY(launch_gemm32(h, s, queries, W32(h, bb + "0.weight"), W32(h, bb + "0.bias"), nullptr, h->dt_h1, Mq, E, E, ACT_RELU));
+    WM_TRY(launch_gemm32(h, s, h->dt_h1, W32(h, bb + "1.weight"), W32(h, bb + "1.bias"), nullptr, h->dt_h2, Mq, E, E, ACT_RELU));
+    WM_TRY(launch_gemm32(h, s, h->dt_h2, W32(h, bb + "2.weight"), W32(h, bb + "2.bias"), nullptr, boxes, Mq, 4, E, ACT_SIGMOID));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int wm_hfc_fft(wm_handle* h, const float* x_dev, float* hfc_dev, int batch, void* stream) {
+    if (h && !h->finalized) { /* the FFT needs no weights */ }
+    if (!h) return fail("wm_hfc_fft: null handle");
+    if (batch <= 0 || batch > h->maxB) return fail("wm_hfc_fft: batch %d outside 1..%d", batch, h->maxB);
+    if (!x_dev || !hfc_dev) return fail("wm_hfc_fft: null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    return fft_impl(h, x_dev, hfc_dev, batch, (hipStream_t)stream);
+}
+
+extern "C" int wm_encoder_forward(wm_handle* h, const float* x_dev, const float* hfc_dev, float* out_dev, int batch, void* stream) {
+    WM_TRY(check_ready(h, batch, "wm_encoder_forward", true, false));
+    if (!x_dev || !hfc_dev || !out_dev) return fail("wm_encoder_forward: null buffer");
+    return encoder_impl(h, x_dev, hfc_dev, out_dev, batch, (hipStream_t)stream);
+}
+
+extern "C" int wm_decoder_forward(wm_handle* h, const float* emb_dev, float* logits_dev, float* boxes_dev, int batch, void* stream) {
+    WM_TRY(check_ready(h, batch, "wm_decoder_forward", false, true));
+    if (!emb_dev || !logits_dev || !boxes_dev) return fail("wm_decoder_forward: null buffer");
+    hipStream_t s = (hipStream_t)stream;
+    // NCHW (B,256,4096) -> token-major (B,4096,256) (transformer.py:83)
+    WM_TRY(launch_simple(h, s, batch * 8.4e6, transpose32_kernel, dim3(T / 64, OUTC / 64, batch), dim3(256), emb_dev, h->emb_nhwc, OUTC, T));
+    return decoder_impl(h, h->emb_nhwc, logits_dev, boxes_dev, batch, s);
+}
+
+extern "C" int wm_postprocess_nms(wm_handle* h, const float* logits_dev, const float* boxes_dev, const float* target_sizes_dev,
+                                  float conf_thr, float score_thr, float iou_thr, wm_box_record* records_dev, int batch, void* stream) {
+    if (!h) return fail("wm_postprocess_nms: null handle");
+    if (batch <= 0) return fail("wm_postprocess_nms: batch %d", batch);
+    if (!logits_dev || !boxes_dev || !target_sizes_dev || !records_dev) return fail("wm_postprocess_nms: null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_simple(h, (hipStream_t)stream, 0.0, postprocess_nms_kernel, dim3(batch), dim3(64), logits_dev, boxes_dev,
+                         target_sizes_dev, conf_thr, score_thr, iou_thr, records_dev);
+}
+
+extern "C" int wm_forward(wm_handle* h, const float* x_dev, const float* target_sizes_dev, float* logits_dev, float* boxes_dev,
+                          wm_box_record* records_dev, int batch, void* stream) {
+    WM_TRY(check_ready(h, batch, "wm_forward", true, true));
+    if (!x_dev) return fail("wm_forward: null input");
+    hipStream_t s = (hipStream_t)stream;
+    WM_TRY(fft_impl(h, x_dev, h->hfc, batch, s));                                          // network.py:61
+    WM_TRY(encoder_impl(h, x_dev, h->hfc, nullptr, batch, s));                             // network.py:65
+    WM_TRY(decoder_impl(h, h->emb_nhwc, h->logits, h->boxes, batch, s));                   // network.py:79-86
+    const float* ts = target_sizes_dev ? target_sizes_dev : h->tsz_default;
+    WM_TRY(launch_simple(h, s, 0.0, postprocess_nms_kernel, dim3(batch), dim3(64), (const float*)h->logits, (const float*)h->boxes, ts,
+                         0.05f, 0.5f, 0.4f, h->records));
+    if (logits_dev) HIP_TRY(hipMemcpyAsync(logits_dev, h->logits, (size_t)batch * NQ * WM_NUM_LOGITS * 4, hipMemcpyDeviceToDevice, s));
+    if (boxes_dev) HIP_TRY(hipMemcpyAsync(boxes_dev, h->boxes, (size_t)batch * NQ * 16, hipMemcpyDeviceToDevice, s));
+    if (records_dev) HIP_TRY(hipMemcpyAsync(records_dev, h->records, (size_t)batch * NQ * sizeof(wm_box_record), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// taps / profiling
+// ---------------------------------------------------------------------------
+extern "C" int wm_set_tap(wm_handle* h, int which) {
+    if (!h) return fail("wm_set_tap: null handle");
+    if (which < -2 || which >= h->depth) return fail("wm_set_tap: %d out of range", which);
+    h->tap_which = which;
+    return 0;
+}
+
+extern "C" int wm_read_tap(wm_handle* h, float* out_dev, int batch, void* stream) {
+    if (!h || !out_dev) return fail("wm_read_tap: null argument");
+    if (!h->tap_buf) return fail("wm_read_tap: no tap captured");
+    if (batch <= 0 || batch > h->maxB) return fail("wm_read_tap: bad batch");
+    HIP_TRY(hipMemcpyAsync(out_dev, h->tap_buf, (size_t)batch * T * h->D * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int wm_profile_enable(wm_handle* h, int on) {
+    if (!h) return fail("wm_profile_enable: null handle");
+    h->prof.on = on != 0;
+    return 0;
+}
+
+extern "C" int wm_profile_reset(wm_handle* h) {
+    if (!h) return fail("wm_profile_reset: null handle");
+    WM_TRY(prof_collect(h));
+    for (auto& a : h->prof.acc) a = wm_kclass_stat{};
+    return 0;
+}
+
+extern "C" int wm_profile_read(wm_handle* h, wm_kclass_stat* out) {
+    if (!h || !out) return fail("wm_profile_read: null argument");
+    WM_TRY(prof_collect(h));
+    for (int i = 0; i < WM_KCLASS_COUNT; ++i) out[i] = h->prof.acc[i];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// single-op entry points
+// ---------------------------------------------------------------------------
+extern "C" int wm_op_cvt_f32_to_16(const float* in_dev, void* out_dev, int64_t n, int precision, void* stream) {
+    if (n % 4) return fail("cvt: n must be a multiple of 4");
+    if (precision == WM_PREC_FP16) hipLaunchKernelGGL(cvt_f32_to_16_kernel<FP16>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, in_dev, (u16*)out_dev, n / 4);
+    else hipLaunchKernelGGL(cvt_f32_to_16_kernel<BF16>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, in_dev, (u16*)out_dev, n / 4);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wm_op_cvt_16_to_f32(const void* in_dev, float* out_dev, int64_t n, int precision, void* stream) {
+    if (precision == WM_PREC_FP16) hipLaunchKernelGGL(cvt_16_to_f32_kernel<FP16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const u16*)in_dev, out_dev, n);
+    else hipLaunchKernelGGL(cvt_16_to_f32_kernel<BF16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const u16*)in_dev, out_dev, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev, int res_mod,
+                            float* out_f32_dev, void* out_16_dev, int M, int N, int K, int act, int precision, void* stream) {
+    return launch_gemm16(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, bias_dev, residual_dev, res_mod, out_f32_dev, out_16_dev, M, N, K, act);
+}
+
+extern "C" int wm_op_gemm32(const float* a_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* out_dev,
+                            int M, int N, int K, int act, void* stream) {
+    return launch_gemm32(nullptr, (hipStream_t)stream, a_dev, w_dev, bias_dev, residual_dev, out_dev, M, N, K, act);
+}
+
+extern "C" int wm_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, float* out_f32_dev,
+                               void* out_16_dev, int64_t rows, int C, int precision, void* stream) {
+    return launch_layernorm(nullptr, (hipStream_t)stream, precision, x_dev, gamma_dev, beta_dev, eps, out_f32_dev, out_16_dev, rows, C);
+}
+
+extern "C" int wm_op_encoder_attention(const void* qkv_dev, const float* qkv_bias_dev, const float* rel_pos_h_dev,
+                                       const float* rel_pos_w_dev, void* out_dev, int batch, int heads, int head_dim, int window,
+                                       int precision, void* stream) {
+    return launch_encoder_attention(nullptr, (hipStream_t)stream, precision, qkv_dev, qkv_bias_dev, rel_pos_h_dev, rel_pos_w_dev, out_dev,
+                                    batch, heads, head_dim, window);
+}
+
+extern "C" int wm_op_mha16(const void* q_dev, int q_stride, const void* k_dev, int k_stride, const void* v_dev, int v_stride,
+                           void* out_dev, int out_stride, int batch, int heads, int head_dim, int nq, int nk, int precision, void* stream) {
+    return launch_mha16(nullptr, (hipStream_t)stream, precision, q_dev, q_stride, k_dev, k_stride, v_dev, v_stride, out_dev, out_stride,
+                        batch, heads, head_dim, nq, nk);
+}
+
+extern "C" int wm_op_mha32(const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, int batch, int heads,
+                           int head_dim, int nq, int nk, void* stream) {
+    return launch_mha32(nullptr, (hipStream_t)stream, q_dev, k_dev, v_dev, out_dev, batch, heads, head_dim, nq, nk);
+}

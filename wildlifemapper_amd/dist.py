@@ -1,0 +1,62 @@
+"""Data-parallel tile sharding and detection collation.
+
+The path shards by tile: tiles are independent (per-image PostProcess, build_sam.py:237;
+per-image NMS, visualize_prediction.py:150-154), weights are replicated, and the only
+exchange is collating detections at the end -- the analogue of the reference's evaluation
+gather (inference.py:240-259 via utils/misc.py:180-220).  Here that is ONE fixed-size
+all-gather of box records (51 slots x 32 B per tile): no pickle, no size pre-exchange.
+One process per GPU; backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+RECORD_FLOATS = 8          # sizeof(wm_box_record) / 4
+SLOTS = 51
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from torchrun's env; initialises the process group if world > 1."""
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_tiles: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of tiles owned by `rank` (first ranks take the remainder)."""
+    q, r = divmod(n_tiles, world)
+    start = rank * q + min(rank, r)
+    return start, start + q + (1 if rank < r else 0)
+
+
+def max_shard(n_tiles: int, world: int) -> int:
+    return (n_tiles + world - 1) // world
+
+
+def all_gather_records(records: torch.Tensor, n_tiles: int, rank: int, world: int) -> torch.Tensor:
+    """records: this rank's (n_local, 51, 8) float32 raw records.  Returns (n_tiles, 51, 8) in global
+    tile order on every rank.  Shards are padded to the largest shard so the collective is fixed-size."""
+    if world == 1:
+        return records
+    cap = max_shard(n_tiles, world)
+    padded = torch.zeros((cap, SLOTS, RECORD_FLOATS), dtype=torch.float32, device=records.device)
+    padded[: records.shape[0]] = records
+    out = torch.empty((world, cap, SLOTS, RECORD_FLOATS), dtype=torch.float32, device=records.device)
+    dist.all_gather_into_tensor(out.view(-1), padded.view(-1))
+    parts: List[torch.Tensor] = []
+    for r in range(world):
+        s, e = shard_range(n_tiles, r, world)
+        parts.append(out[r, : e - s])
+    return torch.cat(parts, dim=0)

@@ -1,0 +1,215 @@
+"""Host-side owner of one native handle (include/wm_hip.h) shared by the drop-in
+nn.Modules.  Pure plumbing: parameter tensors in, device pointers through the
+C-ABI, tensors out.  All arithmetic happens in libwm_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .synth import MODEL_DIMS, ModelDims
+
+
+def default_precision() -> str:
+    return os.environ.get("WM_PRECISION", "bf16").lower()
+
+
+class EngineHub:
+    """Lazily creates / refreshes a wm_handle for the modules registered with it."""
+
+    def __init__(self, embed_dim: int, depth: int, num_heads: int, global_attn_indexes: Iterable[int],
+                 precision: Optional[str] = None, max_batch: Optional[int] = None) -> None:
+        self.embed_dim, self.depth, self.num_heads = int(embed_dim), int(depth), int(num_heads)
+        self.global_attn_indexes = tuple(int(i) for i in global_attn_indexes)
+        self.precision = (precision or default_precision()).lower()
+        if self.precision not in N.PREC_BY_NAME:
+            raise ValueError(f"unknown precision {self.precision!r} (bf16 | fp16)")
+        self.max_batch = int(max_batch or os.environ.get("WM_MAX_BATCH", 0) or 0)
+        self._handle: Optional[C.c_void_p] = None
+        self._device: Optional[torch.device] = None
+        self._sources: Dict[str, torch.nn.Module] = {}      # prefix -> module
+        self._signature: Dict[str, Tuple[int, int]] = {}    # name -> (data_ptr, version)
+
+    # -- registration -------------------------------------------------------
+    def register(self, prefix: str, module: torch.nn.Module) -> None:
+        self._sources[prefix] = module
+
+    def adopt(self, other: "EngineHub") -> None:
+        """Merge the modules of another hub into this one (MedSAM wiring)."""
+        if other is self:
+            return
+        for prefix, mod in other._sources.items():
+            self._sources[prefix] = mod
+            mod._hub = self
+        other.close()
+
+    # -- handle lifetime ----------------------------------------------------
+    def close(self) -> None:
+        if self._handle is not None:
+            N.lib().wm_destroy(self._handle)
+            self._handle = None
+            self._signature = {}
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_precision(self, precision: str) -> None:
+        precision = precision.lower()
+        if precision not in N.PREC_BY_NAME:
+            raise ValueError(precision)
+        if precision != self.precision:
+            self.precision = precision
+            self.close()
+
+    def _create(self, device: torch.device, batch: int) -> None:
+        self.close()
+        cfg = N.WmConfig()
+        cfg.embed_dim, cfg.depth, cfg.num_heads = self.embed_dim, self.depth, self.num_heads
+        cfg.num_global = len(self.global_attn_indexes)
+        for i, g in enumerate(self.global_attn_indexes):
+            cfg.global_attn_indexes[i] = g
+        self.max_batch = max(self.max_batch, batch)
+        cfg.max_batch = self.max_batch
+        cfg.precision = N.PREC_BY_NAME[self.precision]
+        h = C.c_void_p()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        N.check(N.lib().wm_create(C.byref(cfg), idx, C.byref(h)))
+        self._handle, self._device = h, device
+
+    def _named_tensors(self):
+        for prefix, mod in self._sources.items():
+            for k, v in mod.state_dict(keep_vars=True).items():
+                yield prefix + k, v
+
+    def _sync_weights(self) -> None:
+        lib = N.lib()
+        changed = False
+        for name, t in self._named_tensors():
+            sig = (t.data_ptr(), t._version)
+            if self._signature.get(name) == sig:
+                continue
+            host = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+            shape = (C.c_int64 * host.dim())(*host.shape)
+            N.check(lib.wm_load_weight(self._handle, name.encode(), C.c_void_p(host.data_ptr()), shape, host.dim()))
+            self._signature[name] = sig
+            changed = True
+        if changed:
+            N.check(lib.wm_finalize_weights(self._handle))
+
+    def handle(self, device: torch.device, batch: int) -> C.c_void_p:
+        if device.type != "cuda":
+            raise RuntimeError("wildlifemapper_amd runs on a ROCm device only; got " + str(device))
+        if self._handle is None or self._device != device or batch > self.max_batch:
+            self._create(device, batch)
+        self._sync_weights()
+        return self._handle
+
+    # -- the path -----------------------------------------------------------
+    def hfc_fft(self, x: torch.Tensor) -> torch.Tensor:
+        N.require_cuda(x, "hfc_fft input")
+        B = x.shape[0]
+        _check_image(x, 3)
+        if self._handle is None or self._device != x.device or B > self.max_batch:
+            self._create(x.device, B)          # the FFT needs no weights
+        out = torch.empty((B, 1, 1024, 1024), device=x.device, dtype=torch.float32)
+        N.check(N.lib().wm_hfc_fft(self._handle, N.ptr(x), N.ptr(out), B, N.stream_ptr(x.device)))
+        return out
+
+    def encoder_forward(self, x: torch.Tensor, x_hfc: torch.Tensor) -> torch.Tensor:
+        N.require_cuda(x, "encoder input x")
+        N.require_cuda(x_hfc, "encoder input x_hfc")
+        _check_image(x, 3)
+        _check_image(x_hfc, 1)
+        B = x.shape[0]
+        h = self.handle(x.device, B)
+        out = torch.empty((B, 256, 64, 64), device=x.device, dtype=torch.float32)
+        N.check(N.lib().wm_encoder_forward(h, N.ptr(x), N.ptr(x_hfc), N.ptr(out), B, N.stream_ptr(x.device)))
+        return out
+
+    def decoder_forward(self, emb: torch.Tensor) -> Dict[str, torch.Tensor]:
+        N.require_cuda(emb, "decoder input")
+        if emb.dim() != 4 or tuple(emb.shape[1:]) != (256, 64, 64):
+            raise RuntimeError(f"decoder input must be (B,256,64,64), got {tuple(emb.shape)}")
+        B = emb.shape[0]
+        h = self.handle(emb.device, B)
+        logits = torch.empty((B, N.NUM_QUERIES, N.NUM_LOGITS), device=emb.device, dtype=torch.float32)
+        boxes = torch.empty((B, N.NUM_QUERIES, 4), device=emb.device, dtype=torch.float32)
+        N.check(N.lib().wm_decoder_forward(h, N.ptr(emb), N.ptr(logits), N.ptr(boxes), B, N.stream_ptr(emb.device)))
+        return {"pred_logits": logits, "pred_boxes": boxes}
+
+    def forward(self, x: torch.Tensor, target_sizes: Optional[torch.Tensor] = None, want_records: bool = False):
+        """fft -> encoder -> decoder (-> PostProcess + NMS records) in one native call."""
+        N.require_cuda(x, "model input")
+        _check_image(x, 3)
+        B = x.shape[0]
+        h = self.handle(x.device, B)
+        logits = torch.empty((B, N.NUM_QUERIES, N.NUM_LOGITS), device=x.device, dtype=torch.float32)
+        boxes = torch.empty((B, N.NUM_QUERIES, 4), device=x.device, dtype=torch.float32)
+        rec = torch.empty((B, N.NUM_QUERIES, 8), device=x.device, dtype=torch.float32) if want_records else None
+        ts = None
+        if target_sizes is not None:
+            ts = target_sizes.to(device=x.device, dtype=torch.float32).contiguous()
+        N.check(N.lib().wm_forward(h, N.ptr(x), N.ptr(ts), N.ptr(logits), N.ptr(boxes), N.ptr(rec), B, N.stream_ptr(x.device)))
+        out = {"pred_logits": logits, "pred_boxes": boxes}
+        if want_records:
+            out["records"] = rec
+        return out
+
+    def postprocess_nms(self, logits: torch.Tensor, boxes: torch.Tensor, target_sizes: torch.Tensor,
+                        conf_thr: float = 0.05, score_thr: float = 0.5, iou_thr: float = 0.4) -> torch.Tensor:
+        """Returns raw records (B,51,8) float32-viewed: x0,y0,x1,y1,score | int32 label,flags,nms_rank."""
+        N.require_cuda(logits, "pred_logits")
+        N.require_cuda(boxes, "pred_boxes")
+        B = logits.shape[0]
+        if self._handle is None or self._device != logits.device:
+            self._create(logits.device, max(B, 1))
+        ts = target_sizes.to(device=logits.device, dtype=torch.float32).contiguous()
+        rec = torch.empty((B, N.NUM_QUERIES, 8), device=logits.device, dtype=torch.float32)
+        N.check(N.lib().wm_postprocess_nms(self._handle, N.ptr(logits), N.ptr(boxes), N.ptr(ts), conf_thr, score_thr, iou_thr,
+                                           N.ptr(rec), B, N.stream_ptr(logits.device)))
+        return rec
+
+    # -- taps / profiling ---------------------------------------------------
+    def set_tap(self, which: int) -> None:
+        N.check(N.lib().wm_set_tap(self._handle, which))
+
+    def read_tap(self, batch: int) -> torch.Tensor:
+        out = torch.empty((batch, 64, 64, self.embed_dim), device=self._device, dtype=torch.float32)
+        N.check(N.lib().wm_read_tap(self._handle, N.ptr(out), batch, N.stream_ptr(self._device)))
+        return out
+
+    def profile_enable(self, on: bool) -> None:
+        N.check(N.lib().wm_profile_enable(self._handle, int(on)))
+
+    def profile_reset(self) -> None:
+        N.check(N.lib().wm_profile_reset(self._handle))
+
+    def profile_read(self) -> Dict[str, Dict[str, float]]:
+        arr = (N.WmKclassStat * len(N.KCLASS_NAMES))()
+        N.check(N.lib().wm_profile_read(self._handle, arr))
+        return {n: {"launches": int(arr[i].launches), "ms": float(arr[i].ms), "flops": float(arr[i].flops),
+                    "bytes": float(arr[i].bytes)} for i, n in enumerate(N.KCLASS_NAMES)}
+
+
+def _check_image(x: torch.Tensor, chans: int) -> None:
+    if x.dim() != 4 or x.shape[1] != chans or x.shape[2] != 1024 or x.shape[3] != 1024:
+        raise RuntimeError(f"expected (B,{chans},1024,1024), got {tuple(x.shape)}")
+
+
+def split_records(rec: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """(B,51,8) raw records -> named views (int fields reinterpreted)."""
+    ints = rec.view(torch.int32)
+    return {"boxes": rec[..., 0:4], "scores": rec[..., 4], "labels": ints[..., 5].to(torch.int64),
+            "flags": ints[..., 6], "nms_rank": ints[..., 7]}
+
+
+def hub_for(model_type: str, precision: Optional[str] = None, max_batch: Optional[int] = None) -> EngineHub:
+    d: ModelDims = MODEL_DIMS[model_type]
+    return EngineHub(d.embed_dim, d.depth, d.num_heads, d.global_attn_indexes, precision, max_batch)

@@ -1,0 +1,319 @@
+"""Build-owned synthetic weights and tiles (no torch RNG, no libm).
+
+The reference ships no checkpoint, so parity and the bench
+run on seeded synthetic weights and tiles.  Everything here is a pure integer
+hash -> float pipeline (splitmix64 finaliser on a counter), so the same name
+and seed give bit-identical fp32 values in this container, on the GPU box and
+inside the golden-fixture generator.  No transcendental is used: "normal"
+fills are a scaled sum of four uniforms (Irwin-Hall), which is deterministic
+across libm / SIMD dispatch differences.
+
+Model dimensions follow the reference factory
+(wildlifemapper/segment_anything/build_sam.py:19-52, 260-309); state-dict
+names follow SURVEY.md §8b.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+@dataclass(frozen=True)
+class ModelDims:
+    """Encoder dims per model type; everything else is fixed by the factory."""
+    name: str
+    embed_dim: int
+    depth: int
+    num_heads: int
+    global_attn_indexes: Tuple[int, ...]
+    # constants of build_sam.py:266-309 / image_encoder.py:65-87
+    img_size: int = 1024
+    patch: int = 16
+    grid: int = 64            # img_size // patch
+    window: int = 14
+    out_chans: int = 256
+    hfc_dim: int = 1024
+    hfc_heads: int = 8
+    mlp_ratio: int = 4
+    num_queries: int = 51     # num_multimask_outputs(50) + 1, box_decoder.py:53
+    num_logits: int = 8       # num_classes(7) + 1, box_decoder.py:68
+    dec_dim: int = 256
+    dec_heads: int = 8
+    dec_mlp: int = 2048
+    dec_depth: int = 2
+
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.num_heads
+
+
+MODEL_DIMS = {
+    "vit_h": ModelDims("vit_h", 1280, 32, 16, (7, 15, 23, 31)),
+    "vit_l": ModelDims("vit_l", 1024, 24, 16, (5, 11, 17, 23)),
+    "vit_b": ModelDims("vit_b", 768, 12, 12, (2, 5, 8, 11)),
+}
+MODEL_DIMS["default"] = MODEL_DIMS["vit_h"]
+
+
+# ----------------------------------------------------------------------------
+# counter-based generator
+# ----------------------------------------------------------------------------
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _MASK
+    x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+    x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+    return x ^ (x >> np.uint64(31))
+
+
+def _stream_key(seed: int, name: str) -> np.uint64:
+    h = zlib.crc32(name.encode("utf-8")) & 0xFFFFFFFF
+    k = (int(seed) * 0x100000001B3 + h * 0x9E3779B1 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
+    return np.uint64(k)
+
+
+def _uniform01(key: np.uint64, n: int, lane: int = 0, chunk: int = 1 << 24) -> np.ndarray:
+    """n fp32 values in [0,1) with 24-bit resolution; element i uses counter (i, lane)."""
+    out = np.empty(n, dtype=np.float32)
+    with np.errstate(over="ignore"):
+        for s in range(0, n, chunk):
+            e = min(n, s + chunk)
+            ctr = np.arange(s, e, dtype=np.uint64) * np.uint64(4) + np.uint64(lane)
+            bits = _splitmix64(ctr ^ key)
+            out[s:e] = (bits >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+    return out
+
+
+def fill_uniform(seed: int, name: str, shape, lo: float, hi: float) -> np.ndarray:
+    n = int(np.prod(shape))
+    u = _uniform01(_stream_key(seed, name), n)
+    return (np.float32(lo) + u * np.float32(hi - lo)).reshape(shape)
+
+
+def fill_normal(seed: int, name: str, shape, std: float, mean: float = 0.0) -> np.ndarray:
+    """Approximate normal: sqrt(3) * (sum of four U(0,1) - 2), unit variance."""
+    n = int(np.prod(shape))
+    key = _stream_key(seed, name)
+    acc = _uniform01(key, n, 0)
+    for lane in (1, 2, 3):
+        acc += _uniform01(key, n, lane)
+    acc = (acc - np.float32(2.0)) * np.float32(1.7320508075688772)
+    return (np.float32(mean) + acc * np.float32(std)).reshape(shape)
+
+
+# ----------------------------------------------------------------------------
+# state-dict enumeration (names + shapes), SURVEY.md §8b "Weight format"
+# ----------------------------------------------------------------------------
+def weight_shapes(model_type: str = "vit_h") -> "OrderedDict[str, Tuple[int, ...]]":
+    d = MODEL_DIMS[model_type]
+    D, G, hd = d.embed_dim, d.grid, d.head_dim
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    e = "image_encoder."
+    s[e + "pos_embed"] = (1, G, G, D)
+    s[e + "patch_embed.proj.weight"] = (D, 3, d.patch, d.patch)
+    s[e + "patch_embed.proj.bias"] = (D,)
+    s[e + "hfc_embed.proj.weight"] = (d.hfc_dim, 1, d.patch, d.patch)
+    s[e + "hfc_embed.proj.bias"] = (d.hfc_dim,)
+    a = e + "hfc_attn."
+    H = d.hfc_dim
+    s[a + "pos_embed"] = (1, H, G, G)
+    s[a + "proj_hfc.weight"] = (H, H, 1, 1)
+    s[a + "proj_hfc.bias"] = (H,)
+    s[a + "proj_patch.weight"] = (H, D, 1, 1)
+    s[a + "proj_patch.bias"] = (H,)
+    s[a + "cross_attn.in_proj_weight"] = (3 * H, H)
+    s[a + "cross_attn.in_proj_bias"] = (3 * H,)
+    s[a + "cross_attn.out_proj.weight"] = (H, H)
+    s[a + "cross_attn.out_proj.bias"] = (H,)
+    for nm in ("linear1", "linear2"):
+        s[a + nm + ".weight"] = (H, H)
+        s[a + nm + ".bias"] = (H,)
+    for nm in ("norm1", "norm2"):
+        s[a + nm + ".weight"] = (H,)
+        s[a + nm + ".bias"] = (H,)
+    s[a + "proj_back.weight"] = (D, H, 1, 1)
+    s[a + "proj_back.bias"] = (D,)
+    for i in range(d.depth):
+        b = f"{e}blocks.{i}."
+        size = G if i in d.global_attn_indexes else d.window
+        s[b + "norm1.weight"] = (D,)
+        s[b + "norm1.bias"] = (D,)
+        s[b + "attn.rel_pos_h"] = (2 * size - 1, hd)
+        s[b + "attn.rel_pos_w"] = (2 * size - 1, hd)
+        s[b + "attn.qkv.weight"] = (3 * D, D)
+        s[b + "attn.qkv.bias"] = (3 * D,)
+        s[b + "attn.proj.weight"] = (D, D)
+        s[b + "attn.proj.bias"] = (D,)
+        s[b + "norm2.weight"] = (D,)
+        s[b + "norm2.bias"] = (D,)
+        s[b + "mlp.lin1.weight"] = (d.mlp_ratio * D, D)
+        s[b + "mlp.lin1.bias"] = (d.mlp_ratio * D,)
+        s[b + "mlp.lin2.weight"] = (D, d.mlp_ratio * D)
+        s[b + "mlp.lin2.bias"] = (D,)
+    C = d.out_chans
+    s[e + "neck.0.weight"] = (C, D, 1, 1)
+    s[e + "neck.1.weight"] = (C,)
+    s[e + "neck.1.bias"] = (C,)
+    s[e + "neck.2.weight"] = (C, C, 3, 3)
+    s[e + "neck.3.weight"] = (C,)
+    s[e + "neck.3.bias"] = (C,)
+
+    s["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"] = (2, d.dec_dim // 2)
+
+    m = "mask_decoder."
+    E = d.dec_dim
+
+    def attn(prefix: str, internal: int) -> None:
+        for p in ("q_proj", "k_proj", "v_proj"):
+            s[prefix + p + ".weight"] = (internal, E)
+            s[prefix + p + ".bias"] = (internal,)
+        s[prefix + "out_proj.weight"] = (E, internal)
+        s[prefix + "out_proj.bias"] = (E,)
+
+    for i in range(d.dec_depth):
+        L = f"{m}transformer.layers.{i}."
+        attn(L + "self_attn.", E)
+        s[L + "norm1.weight"] = (E,)
+        s[L + "norm1.bias"] = (E,)
+        attn(L + "cross_attn_token_to_image.", E // 2)
+        s[L + "norm2.weight"] = (E,)
+        s[L + "norm2.bias"] = (E,)
+        s[L + "mlp.lin1.weight"] = (d.dec_mlp, E)
+        s[L + "mlp.lin1.bias"] = (d.dec_mlp,)
+        s[L + "mlp.lin2.weight"] = (E, d.dec_mlp)
+        s[L + "mlp.lin2.bias"] = (E,)
+        s[L + "norm3.weight"] = (E,)
+        s[L + "norm3.bias"] = (E,)
+        s[L + "norm4.weight"] = (E,)
+        s[L + "norm4.bias"] = (E,)
+        attn(L + "cross_attn_image_to_token.", E // 2)
+    attn(m + "transformer.final_attn_token_to_image.", E // 2)
+    s[m + "transformer.norm_final_attn.weight"] = (E,)
+    s[m + "transformer.norm_final_attn.bias"] = (E,)
+    s[m + "iou_token.weight"] = (1, E)
+    s[m + "mask_tokens.weight"] = (d.num_queries, E)
+    for head, out in (("class_embed", d.num_logits), ("bbox_embed", 4)):
+        dims = [E, E, E, out]
+        for j in range(3):
+            s[f"{m}{head}.layers.{j}.weight"] = (dims[j + 1], dims[j])
+            s[f"{m}{head}.layers.{j}.bias"] = (dims[j + 1],)
+    return s
+
+
+def _is_norm(name: str) -> bool:
+    parts = name.split(".")
+    leaf_parent = parts[-2]
+    if leaf_parent.startswith("norm"):
+        return True
+    # neck.1 / neck.3 are LayerNorm2d
+    return len(parts) >= 3 and parts[-3] == "neck" and leaf_parent in ("1", "3")
+
+
+def make_weight(name: str, shape, seed: int = 0, profile: str = "baseline") -> np.ndarray:
+    """Fill rule per SURVEY.md §8d: non-zero pos/rel-pos tables on purpose."""
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf in ("pos_embed", "rel_pos_h", "rel_pos_w"):
+        return fill_normal(seed, name, shape, 0.02)
+    if name.endswith("positional_encoding_gaussian_matrix"):
+        return fill_normal(seed, name, shape, 1.0)
+    if name.endswith("mask_tokens.weight") or name.endswith("iou_token.weight"):
+        return fill_normal(seed, name, shape, 1.0)
+    if _is_norm(name):
+        if leaf == "weight":
+            return fill_uniform(seed, name, shape, 0.9, 1.1)
+        return fill_uniform(seed, name, shape, -0.02, 0.02)
+    if name.endswith("bbox_embed.layers.2.bias"):
+        # (cx, cy, w, h) pre-sigmoid: keep centres spread, make boxes ~12% of the tile
+        return fill_uniform(seed, name, shape, -0.02, 0.02) + np.asarray([0, 0, -2, -2], dtype=np.float32)
+    if leaf in ("bias", "in_proj_bias"):
+        return fill_uniform(seed, name, shape, -0.02, 0.02)
+    # Linear / Conv weight: U(-a, a), a = 1/sqrt(fan_in)
+    fan_in = int(np.prod(shape[1:]))
+    a = 1.0 / np.sqrt(fan_in)
+    w = fill_uniform(seed, name, shape, -a, a)
+    gain = _decoder_gain(name, profile)
+    if gain != 1.0:
+        w = w * np.float32(gain)
+    return w
+
+
+PROFILES = ("baseline", "sensitive")
+
+
+def _decoder_gain(name: str, profile: str = "baseline") -> float:
+    """Head / cross-attention gains of the synthetic decoder.
+
+    baseline  - SURVEY.md §8d fills, with the class head x32 and the box head x8
+                so scores straddle the 0.05 / 0.5 cuts and boxes spread over the
+                tile (the x8 suggested there leaves every score below 0.5, so the
+                NMS step would see no boxes).  Last-layer gains do not change
+                relative logit error.
+    sensitive - additionally makes the token->image softmax peaky (q/k x2,
+                v/out x2) so logits move by O(std) between tiles; it amplifies
+                encoder error ~4x into the logits and is the stricter
+                parity profile (DESIGN.md "Precision").
+    """
+    if name.endswith("class_embed.layers.2.weight"):
+        return 32.0
+    if name.endswith("bbox_embed.layers.2.weight"):
+        return 8.0
+    if profile == "sensitive" and "token_to_image" in name and name.endswith(
+            ("q_proj.weight", "k_proj.weight", "v_proj.weight", "out_proj.weight")):
+        return 2.0
+    return 1.0
+
+
+def make_state_dict(model_type: str = "vit_h", seed: int = 0, only_prefix: str | None = None,
+                    profile: str = "baseline") -> "OrderedDict[str, np.ndarray]":
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in weight_shapes(model_type).items():
+        if only_prefix is not None and not name.startswith(only_prefix):
+            continue
+        out[name] = make_weight(name, shape, seed, profile)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# tiles, SURVEY.md §8d "Configs -> concrete synthetic inputs"
+# ----------------------------------------------------------------------------
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def make_tile_u8(t: int, size: int = 1024, smooth: bool = False) -> np.ndarray:
+    """uint8 RGB (size,size,3) for global tile index t (seed 1234+t).
+
+    The default is the i.i.d. U{0..255} tile of SURVEY.md §8d / BASELINE.md §3.
+    `smooth=True` mixes a low-frequency block pattern with the noise so the
+    FFT high-pass (network.py:36-57) sees both pass-band and stop-band energy
+    (used by some parity tests).
+    """
+    key = _stream_key(1234 + int(t), "tile")
+    n = size * size * 3
+    noise = (_uniform01(key, n) * np.float32(256.0)).astype(np.int32).reshape(size, size, 3)
+    if not smooth:
+        return np.clip(noise, 0, 255).astype(np.uint8)
+    blk = 32
+    g = size // blk
+    coarse = (_uniform01(key, g * g * 3, lane=1) * np.float32(256.0)).astype(np.int32).reshape(g, g, 3)
+    coarse = np.repeat(np.repeat(coarse, blk, axis=0), blk, axis=1)
+    mixed = (coarse * 3 + noise) // 4
+    return np.clip(mixed, 0, 255).astype(np.uint8)
+
+
+def normalize_tile(u8: np.ndarray) -> np.ndarray:
+    """uint8 HWC -> fp32 CHW, /255 then ImageNet mean/std (dataloader_coco.py:288-291)."""
+    x = u8.astype(np.float32) / np.float32(255.0)
+    mean = np.asarray(IMAGENET_MEAN, dtype=np.float32)
+    std = np.asarray(IMAGENET_STD, dtype=np.float32)
+    x = (x - mean) / std
+    return np.ascontiguousarray(x.transpose(2, 0, 1))
+
+
+def make_batch(first_tile: int, count: int, size: int = 1024, smooth: bool = False) -> np.ndarray:
+    return np.stack([normalize_tile(make_tile_u8(first_tile + i, size, smooth)) for i in range(count)])
