@@ -54,7 +54,7 @@ def _model(mt, prec):
         sam, crit, post = sam_model_registry[mt](None, None)
         m = MedSAM(sam.image_encoder, sam.mask_decoder, sam.prompt_encoder).eval()
         m.load_state_dict(sd, strict=True)
-        _MODELS[mt] = (m, post)
+        _MODELS[mt] = (m, post["bbox"])
     m, post = _MODELS[mt]
     m._hub.set_precision(prec)
     return m, post
