@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Throughput bench of the WildlifeMapper inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one batch of synthetic 1024x1024 tiles that is already
+resident in HBM: FFT high-pass -> ViT-H encoder -> detection decoder -> PostProcess + NMS
+(`--workload full`, the default), or the encoder alone (`--workload encoder` = BASELINE.json
+configs[1] literally).  Default batch is 4 tiles per GPU (configs[1]); `--batch 16` gives configs[2].
+With N > 1 tiles shard data-parallel, one process per GPU, and every step ends with the single
+fixed-size RCCL all-gather of box records (dist.py); per-GPU work is constant -> weak scaling.
+
+One JSON line on rank 0.  `roofline` is for the dominant kernel class (the 16-bit MFMA GEMM):
+algorithmic FLOPs of its launches / their summed duration, measured with HIP events on the
+launch stream in a second pass of the same steps (so the headline timing carries no event overhead).
+`cpu_baseline` times the CPU oracle (fp32 torch port of the reference) on ONE ViT-H tile.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+from wildlifemapper_amd import dist as wdist
+from wildlifemapper_amd import synth
+
+# algorithmic FLOPs per tile (useful work only)
+FLOPS_FULL = {"vit_h": 5797.8e9, "vit_b": 1115.96e9 + 3.55e9}
+FLOPS_ENC = {"vit_h": 5794.3e9, "vit_b": 1115.96e9}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0}      # MI355X dense MFMA peak (MI355X_MICROARCH.md)
+
+
+def build_model(model_type: str, precision: str, device: torch.device):
+    from wildlifemapper_amd.segment_anything import sam_model_registry
+    from wildlifemapper_amd.segment_anything.network import MedSAM
+    sam, _, post = sam_model_registry[model_type](None, None)
+    model = MedSAM(sam.image_encoder, sam.mask_decoder, sam.prompt_encoder).eval()
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(model_type).items()}
+    model.load_state_dict(sd, strict=True)
+    model._hub.set_precision(precision)
+    return model, sd
+
+
+def cpu_baseline(model_type: str, sd) -> dict:
+    """Oracle (CPU port of the reference, fp32) on one tile; checker code used here only as a timed baseline."""
+    from oracle import wm_oracle as O
+    x = torch.from_numpy(synth.make_batch(0, 1))
+    cfg = O.OracleCfg.from_model_type(model_type)
+    threads = torch.get_num_threads()
+    t0 = time.time()
+    O.model_forward(x, sd, cfg)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "tiles/s", "cores": threads, "kind": "port",
+            "sample": f"1 {model_type} tile, full path fp32 (fft+encoder+decoder), {dt:.1f} s, torch CPU {threads} threads"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="tiles per GPU per step")
+    ap.add_argument("--model", default="vit_h")
+    ap.add_argument("--precision", default=os.environ.get("WM_PRECISION", "bf16"))
+    ap.add_argument("--workload", default="full", choices=["full", "encoder"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank, world, local = wdist.init_from_env("nccl")
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    model, sd = build_model(a.model, a.precision, device)
+    hub = model._hub
+    B = a.batch
+    n_tiles = B * world
+    first, _ = wdist.shard_range(n_tiles, rank, world)
+    x = torch.from_numpy(synth.make_batch(first, B)).to(device)         # resident before timing
+    ts = torch.full((B, 2), 1024.0, device=device)
+    hfc = model.fft(x) if a.workload == "encoder" else None
+
+    def step():
+        if a.workload == "encoder":
+            return model.image_encoder(x, hfc)
+        out = model.detect(x, ts)
+        if world > 1:
+            return wdist.all_gather_records(out["records"], n_tiles, rank, world)
+        return out["records"]
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        sync()
+        elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    tiles_per_s = n_tiles * a.steps / elapsed
+
+    roofline = None
+    classes = None
+    if not a.no_roofline and rank == 0:
+        hub.profile_enable(True)
+        hub.profile_reset()
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            torch.cuda.synchronize(device)
+            prof_elapsed = time.perf_counter() - t1
+        st = hub.profile_read()
+        hub.profile_enable(False)
+        g = st["gemm16"]
+        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        peak = PEAK_TFLOPS[a.precision if a.precision in PEAK_TFLOPS else "bf16"]
+        roofline = {"bound": "mfma", "kernel": "gemm16_kernel", "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "launches_per_step": g["launches"] // a.steps,
+                    "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
+                    "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
+                    "ms_per_step_with_events": round(prof_elapsed / a.steps * 1e3, 3)}
+        classes = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["launches"] // a.steps,
+                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
+                   for k, v in st.items()}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        flops_tile = (FLOPS_ENC if a.workload == "encoder" else FLOPS_FULL).get(a.model)
+        line = {
+            "metric": "1024x1024 tiles/sec (whole node)", "value": round(tiles_per_s, 3), "unit": "tiles/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": (f"{a.model} {'encoder only' if a.workload == 'encoder' else 'full path fft+encoder+decoder+PostProcess/NMS'}"
+                                    f", {a.precision} MFMA, batch={B} tiles/GPU of 1024x1024x3 (BASELINE.json configs[1] batch"
+                                    f"{'' if a.workload == 'encoder' else ', configs[2]/[3] scope'})"),
+                       "tiles_per_step": n_tiles, "parallelism": f"dp{world} tile shard" + (", RCCL all-gather of box records" if world > 1 and a.workload == "full" else ""),
+                       "weights": "seed 0 synthetic (random init)"},
+            "model_tflops": round(tiles_per_s * flops_tile / 1e12, 1) if flops_tile else None,
+            "frac_of_mfma_peak_whole_path": round(tiles_per_s * flops_tile / 1e12 / (PEAK_TFLOPS.get(a.precision, 2500.0) * world), 4) if flops_tile else None,
+            "roofline": roofline, "kernel_classes": classes,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(a.model, sd)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
