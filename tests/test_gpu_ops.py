@@ -62,8 +62,8 @@ def test_gemm16_identity_asymmetric():
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("act", [0, 1, 2])
-def test_gemm16_epilogue(prec, act):
-    M, N, K = 384, 256, 320
+@pytest.mark.parametrize("M,N,K", [(384, 256, 320), (512, 256, 320), (8192, 1280, 192)])   # v1 tile, v2 BN=128, v2 BN=160
+def test_gemm16_epilogue(prec, act, M, N, K):
     a = G.to16(torch.randn(M, K, device=G.dev()), prec)
     w = G.to16(torch.randn(N, K, device=G.dev()) / math.sqrt(K), prec)
     bias = torch.randn(N, device=G.dev())

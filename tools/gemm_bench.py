@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Dev tool: time the 16-bit MFMA GEMM on the block shapes (random data), optionally under rocprofv3."""
+import argparse, math, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+import gpu_util as G
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--batch", type=int, default=4)
+ap.add_argument("--shapes", default="qkv,proj,lin1,lin2")
+ap.add_argument("--prec", default="bf16")
+a = ap.parse_args()
+M = a.batch * 4096
+shapes = {"qkv": (M, 3840, 1280), "proj": (M, 1280, 1280), "lin1": (M, 5120, 1280), "lin2": (M, 1280, 5120),
+          "hfc": (M, 1024, 1024), "neck": (M, 256, 2304)}
+dev = G.dev()
+for name in a.shapes.split(","):
+    m, n, k = shapes[name]
+    A = G.to16(torch.randn(m, k, device=dev), a.prec)
+    W = G.to16(torch.randn(n, k, device=dev) / math.sqrt(k), a.prec)
+    bias = torch.randn(n, device=dev)
+    for _ in range(3):
+        G.gemm16(A, W, bias, prec=a.prec, want32=False, want16=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        G.gemm16(A, W, bias, prec=a.prec, want32=False, want16=True)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / a.iters
+    print(f"{name:5s} M={m} N={n} K={k}: {us:8.1f} us  {2.0*m*n*k/us/1e6:8.1f} TFLOP/s", flush=True)

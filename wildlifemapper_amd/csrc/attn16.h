@@ -360,27 +360,39 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
 // ---------------------------------------------------------------------------
 // Window attention: one workgroup per (tile, window, head); all 196 keys of the
 // window (incl. padded tokens, whose k/v are the qkv bias) resident in LDS.
-// grid (25, heads, batch), 256 threads; each wave takes query blocks w, w+4.
+// grid (25, heads, batch), 448 threads = 7 waves, wave w owns query slots 32w..32w+31.
+//
+// Rel-pos bias per wave: T[c][i] = q_c . table[i] by one MFMA pass over the 64-row
+// table image (rel_h rows 0..26, rel_w rows 32..58), staged per wave in LDS; each
+// lane then gathers its query's 14 + 14 values U[kh] = T[qh-kh+13], V[kw] = T[32+qw-kw+13]
+// into registers.  The key loop is fully unrolled, so a score element's (kh,kw)
+// are compile-time constants per lane half and the bias is two register selects.
 // ---------------------------------------------------------------------------
 template <int HD> struct WindowLds {
     using G = AttnGeom<HD>;
     static constexpr int NKEY = 224;                                       // 196 padded to 7 x 32
+    static constexpr int NWAVE = 7;
     static constexpr int K_BYTES = NKEY * G::KS, V_BYTES = NKEY * G::VS;
     static constexpr int TAB_BYTES = 64 * G::KS;                           // rel_h rows 0..26, rel_w rows 32..58
-    static constexpr int T_BYTES = 4 * 32 * 65 * 4;                        // per wave [query][65] fp32
+    static constexpr int T_BYTES = NWAVE * 32 * 65 * 4;                    // per wave [query][65] fp32
     static constexpr int K_OFF = 0, V_OFF = K_BYTES, TAB_OFF = V_OFF + V_BYTES, T_OFF = TAB_OFF + TAB_BYTES;
     static constexpr int TOTAL = T_OFF + T_BYTES;
 };
 
 template <class T, int HD>
-__global__ __launch_bounds__(256, 1) void attn_window_kernel(AttnArgs p) {
+__global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p) {
     using G = AttnGeom<HD>;
     using L = WindowLds<HD>;
-    constexpr int WS = 14, GRID = 64, NWIN = 5, NTOK = WS * WS;
+    constexpr int WS = 14, GRID = 64, NWIN = 5, NTOK = WS * WS, NTHR = 448;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int win = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    // 1-D grid, XCD-remapped so that the heads of one window (which read the same qkv rows) are
+    // neighbours on one XCD / one L2
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = lid % p.heads;
+    const int win = (lid / p.heads) % (NWIN * NWIN);
+    const int b = lid / (p.heads * NWIN * NWIN);
     const int wy = win / NWIN, wx = win % NWIN;
     const int D = p.heads * HD;
     const float c1 = p.scale * 1.44269504088896340736f;
@@ -394,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void attn_window_kernel(AttnArgs p) {
     const u16* base = p.q + ((size_t)b * GRID * GRID) * p.q_stride + head * HD;   // packed qkv: q at +0, k at +D, v at +2D
 
     // ---- stage K, V (all 224 rows; rows >= 196 zero) and the two rel-pos tables ----
-    for (int e = tid; e < L::NKEY * G::CH; e += 256) {
+    for (int e = tid; e < L::NKEY * G::CH; e += NTHR) {
         const int key = e / G::CH, ch = e % G::CH;
         s16x8 kv8 = s16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv8 = kv8;
         if (key < NTOK) {
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(256, 1) void attn_window_kernel(AttnArgs p) {
         *(s16x8*)(sK + key * G::KS + ch * 16) = kv8;
         *(s16x8*)(sV + key * G::VS + ch * 16) = vv8;
     }
-    for (int e = tid; e < 64 * (HD / 4); e += 256) {
+    for (int e = tid; e < 64 * (HD / 4); e += NTHR) {
         const int row = e / (HD / 4), c4 = e % (HD / 4);
         const int tr = row & 31;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -428,57 +440,61 @@ __global__ __launch_bounds__(256, 1) void attn_window_kernel(AttnArgs p) {
         for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
         *(typename T::vec4*)(sTab + row * G::KS + c4 * 8) = o;
     }
+
+    // this wave's 32 query slots
+    const int qi = wave * 32 + c;                         // slot in the window (0..223)
+    const int qh = qi / WS, qw = qi - qh * WS;
+    const int y = wy * WS + qh, x = wx * WS + qw;
+    const bool qvalid = (qi < NTOK) && (y < GRID) && (x < GRID);
+    const size_t tok = qvalid ? (size_t)(y * GRID + x) : 0;
+    typename T::vec8 qf[G::NKS];
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks)
+        qf[ks] = *(const typename T::vec8*)(base + tok * p.q_stride + 16 * ks + 8 * h);
     __syncthreads();
 
-    for (int qblk = wave; qblk < 7; qblk += 4) {
-        const int qi = qblk * 32 + c;                     // query slot in the window (0..223)
-        const int qh = qi / WS, qw = qi % WS;
-        const int y = wy * WS + qh, x = wx * WS + qw;
-        const bool qvalid = (qi < NTOK) && (y < GRID) && (x < GRID);
-        const size_t tok = qvalid ? (size_t)(y * GRID + x) : 0;
-        typename T::vec8 qf[G::NKS];
+    // T[c][i]: i<32 -> q.rel_h[i], i>=32 -> q.rel_w[i-32], pre-divided by the softmax scale
+    float U[WS], V[WS];
+    {
+        f32x16 acc[2];
 #pragma unroll
-        for (int ks = 0; ks < G::NKS; ++ks)
-            qf[ks] = *(const typename T::vec8*)(base + tok * p.q_stride + 16 * ks + 8 * h);
-
-        // T[c][i]: i<32 -> q.rel_h[i], i>=32 -> q.rel_w[i-32]  (one 64-row "key tile" of table rows)
-        {
-            f32x16 acc[2];
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        qk_tile<T, HD, 2>(acc, qf, sTab, lane);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-            qk_tile<T, HD, 2>(acc, qf, sTab, lane);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int il = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    sT[c * 65 + il] = acc[t][r] * inv_scale;
-                }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-        }
-
-        SoftmaxState<G::NDT> st;
-        st.init();
-#pragma unroll 1
-        for (int j = 0; j < 7; ++j) {
-            f32x16 s[1];
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int kh = key / WS, kw = key - kh * WS;
-                float bias = 0.f;
-                if (key < NTOK && qi < NTOK) bias = sT[c * 65 + (qh - kh + WS - 1)] + sT[c * 65 + 32 + (qw - kw + WS - 1)];
-                s[0][r] = bias;
+                const int il = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                sT[c * 65 + il] = acc[t][r] * inv_scale;
             }
-            qk_tile<T, HD, 1>(s, qf, sK + j * 32 * G::KS, lane);
-            softmax_pv<T, HD, 1>(st, s, c1, NTOK - 32 * j, sV + j * 32 * G::VS, lane);
+        // table rows 27..31 are zero, so out-of-window slots (qh, qw up to 15) read zeros
+#pragma unroll
+        for (int k = 0; k < WS; ++k) {
+            U[k] = sT[c * 65 + (qh - k + WS - 1)];
+            V[k] = sT[c * 65 + 32 + (qw - k + WS - 1)];
         }
-        u16* orow = p.out + ((size_t)b * GRID * GRID + tok) * p.out_stride + head * HD;
-        store_out<T, HD>(st, orow, lane, qvalid);
-        __builtin_amdgcn_s_waitcnt(0xc07f);
     }
+
+    SoftmaxState<G::NDT> st;
+    st.init();
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        f32x16 s[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // key index of this element for lane half 0 / 1: compile-time after unrolling
+            const int k0 = 32 * j + (r & 3) + 8 * (r >> 2), k1 = k0 + 4;
+            const float b0 = k0 < NTOK ? U[(k0 < NTOK ? k0 : 0) / WS] + V[(k0 < NTOK ? k0 : 0) % WS] : 0.f;
+            const float b1 = k1 < NTOK ? U[(k1 < NTOK ? k1 : 0) / WS] + V[(k1 < NTOK ? k1 : 0) % WS] : 0.f;
+            s[0][r] = h ? b1 : b0;
+        }
+        qk_tile<T, HD, 1>(s, qf, sK + j * 32 * G::KS, lane);
+        softmax_pv<T, HD, 1>(st, s, c1, NTOK - 32 * j, sV + j * 32 * G::VS, lane);
+    }
+    u16* orow = p.out + ((size_t)b * GRID * GRID + tok) * p.out_stride + head * HD;
+    store_out<T, HD>(st, orow, lane, qvalid);
 }
 
 }  // namespace wm

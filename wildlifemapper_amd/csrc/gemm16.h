@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args p) {
             }
             if (p.act == ACT_GELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
             } else if (p.act == ACT_RELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -15,6 +16,7 @@
 #include "dec_kernels.h"
 #include "fft_kernels.h"
 #include "gemm16.h"
+#include "gemm16_v2.h"
 #include "gemm32.h"
 #include "misc_kernels.h"
 #include "wm_common.h"
@@ -196,12 +198,37 @@ int launch_gemm16_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     return 0;
 }
 
+template <class T16, int BN>
+int launch_gemm16v2_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v2_kernel<T16, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, G2<BN>::LDS));
+        attr_set = true;
+    }
+    const int grid = (a.M / 256) * (a.N / BN);
+    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
+               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
+    hipLaunchKernelGGL((gemm16v2_kernel<T16, BN>), dim3(grid), dim3(512), G2<BN>::LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// fraction of the last round of 256 one-per-CU workgroups that is filled
+static double round_eff(long tiles) { return (double)tiles / (double)(((tiles + 255) / 256) * 256); }
+
 int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias,
                   const float* res, int res_mod, float* out32, void* out16, int M, int N, int K, int act) {
     if (M <= 0 || N <= 0 || K <= 0 || M % G16_BM || N % G16_BN || K % G16_BK)
         return fail("gemm16: shape M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, G16_BM, G16_BN, G16_BK);
     if (!out32 && !out16) return fail("gemm16: no output");
     Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act};
+    static const int force_v1 = getenv("WM_GEMM_V1") ? atoi(getenv("WM_GEMM_V1")) : 0;
+    if (M % 256 == 0 && !force_v1) {
+        const bool can160 = N % 160 == 0;
+        const bool use160 = can160 && round_eff((long)(M / 256) * (N / 160)) >= round_eff((long)(M / 256) * (N / 128)) - 1e-9;
+        if (use160) return prec == WM_PREC_FP16 ? launch_gemm16v2_t<FP16, 160>(h, s, a) : launch_gemm16v2_t<BF16, 160>(h, s, a);
+        return prec == WM_PREC_FP16 ? launch_gemm16v2_t<FP16, 128>(h, s, a) : launch_gemm16v2_t<BF16, 128>(h, s, a);
+    }
     return prec == WM_PREC_FP16 ? launch_gemm16_t<FP16>(h, s, a) : launch_gemm16_t<BF16>(h, s, a);
 }
 
@@ -272,7 +299,7 @@ int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
     }
     // useful work only: 4096 real queries x 196 keys
     Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);
-    hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(25, a.heads, batch), dim3(256), L::TOTAL, s, a);
+    hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(25 * a.heads * batch), dim3(448), L::TOTAL, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -62,8 +62,25 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// exact-erf GELU of common.py:26 (nn.GELU default).  Two forms:
+//   gelu_erf      - libm erff, used where the result stays fp32 (gemm32);
+//   gelu_erf_fast - Abramowitz-Stegun 7.1.26 erf (|abs err| <= 1.5e-7), ~15 VALU instead of ~50; used in the
+//                   16-bit GEMM epilogue, whose output is rounded to 2^-9 / 2^-12 relative anyway.
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = 1.0f - poly * t * e;
+    const float erf = x < 0.f ? -erf_abs : erf_abs;
+    return 0.5f * x * (1.0f + erf);
 }
 
 // XCD-aware block remap (bijective for any grid size): blocks that share an XCD
