@@ -138,7 +138,7 @@ def main() -> None:
         g = st["gemm16"]
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         peak = PEAK_TFLOPS[a.precision if a.precision in PEAK_TFLOPS else "bf16"]
-        roofline = {"bound": "mfma", "kernel": "gemm16_kernel", "achieved": round(achieved, 2), "peak": peak,
+        roofline = {"bound": "mfma", "kernel": "gemm16v2_kernel<T,160|128> (all 16-bit MFMA GEMM launches)", "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                     "launches_per_step": g["launches"] // a.steps,
                     "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),

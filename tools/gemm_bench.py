@@ -11,23 +11,32 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--shapes", default="qkv,proj,lin1,lin2")
 ap.add_argument("--prec", default="bf16")
+ap.add_argument("--custom", default="", help="semicolon-separated M,N,K triples")
+ap.add_argument("--act", type=int, default=0)
+ap.add_argument("--f32out", action="store_true")
 a = ap.parse_args()
 M = a.batch * 4096
 shapes = {"qkv": (M, 3840, 1280), "proj": (M, 1280, 1280), "lin1": (M, 5120, 1280), "lin2": (M, 1280, 5120),
           "hfc": (M, 1024, 1024), "neck": (M, 256, 2304)}
 dev = G.dev()
-for name in a.shapes.split(","):
+names = a.shapes.split(",")
+if a.custom:
+    names = []
+    for i, t in enumerate(a.custom.split(";")):
+        shapes[f"c{i}"] = tuple(int(v) for v in t.split(","))
+        names.append(f"c{i}")
+for name in names:
     m, n, k = shapes[name]
     A = G.to16(torch.randn(m, k, device=dev), a.prec)
     W = G.to16(torch.randn(n, k, device=dev) / math.sqrt(k), a.prec)
     bias = torch.randn(n, device=dev)
     for _ in range(3):
-        G.gemm16(A, W, bias, prec=a.prec, want32=False, want16=True)
+        G.gemm16(A, W, bias, act=a.act, prec=a.prec, want32=a.f32out, want16=not a.f32out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
-        G.gemm16(A, W, bias, prec=a.prec, want32=False, want16=True)
+        G.gemm16(A, W, bias, act=a.act, prec=a.prec, want32=a.f32out, want16=not a.f32out)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.iters

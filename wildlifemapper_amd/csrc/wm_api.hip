@@ -216,14 +216,20 @@ int launch_gemm16v2_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
 // fraction of the last round of 256 one-per-CU workgroups that is filled
 static double round_eff(long tiles) { return (double)tiles / (double)(((tiles + 255) / 256) * 256); }
 
+// WM_GEMM_MODE: 0 = auto, 1 = 128x128 kernel only (A/B testing)
+static int gemm_mode() {
+    static const int m = getenv("WM_GEMM_MODE") ? atoi(getenv("WM_GEMM_MODE")) : 0;
+    return m;
+}
+
 int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias,
                   const float* res, int res_mod, float* out32, void* out16, int M, int N, int K, int act) {
     if (M <= 0 || N <= 0 || K <= 0 || M % G16_BM || N % G16_BN || K % G16_BK)
         return fail("gemm16: shape M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, G16_BM, G16_BN, G16_BK);
     if (!out32 && !out16) return fail("gemm16: no output");
     Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act};
-    static const int force_v1 = getenv("WM_GEMM_V1") ? atoi(getenv("WM_GEMM_V1")) : 0;
-    if (M % 256 == 0 && !force_v1) {
+    const int mode = gemm_mode();
+    if (M % 256 == 0 && mode != 1) {
         const bool can160 = N % 160 == 0;
         const bool use160 = can160 && round_eff((long)(M / 256) * (N / 160)) >= round_eff((long)(M / 256) * (N / 128)) - 1e-9;
         if (use160) return prec == WM_PREC_FP16 ? launch_gemm16v2_t<FP16, 160>(h, s, a) : launch_gemm16v2_t<BF16, 160>(h, s, a);
