@@ -6,8 +6,9 @@ Tolerances.  north_star asks for logits within 1e-3 relative of the reference CP
 identical box indices after NMS.  "Relative" is measured as ||x - ref||_2 / ||ref||_2 over the
 (B,51,8) logits.  Operand precision sets what is reachable (DESIGN.md "Precision"):
   fp16 operands: 1e-3 on logits on both weight profiles, identical NMS indices;
-  bf16 operands: 8-bit mantissa -> ~3e-3 per GEMM; logits are checked at 2.5e-3 on the baseline
-                 profile and the embedding at 1e-2.
+  bf16 operands (transformer blocks in bf16; stem, HFC adaptor and neck always run fp16 operands):
+                 1e-3 on logits on the baseline profile (measured 8.3e-4 ViT-H, 4.7e-4 ViT-B), identical NMS
+                 indices; the embedding itself is checked at 5e-3 (8-bit mantissas give ~3e-3 per GEMM).
 """
 import os
 
@@ -25,8 +26,8 @@ from wildlifemapper_amd.segment_anything.network import MedSAM
 from wildlifemapper_amd.segment_anything.utils.misc import NestedTensor, nested_tensor_from_tensor_list
 import gpu_util as G
 
-LOGIT_TOL = {"fp16": 1e-3, "bf16": 2.5e-3}
-EMB_TOL = {"fp16": 2e-3, "bf16": 1e-2}
+LOGIT_TOL = {"fp16": 1e-3, "bf16": 1e-3}
+EMB_TOL = {"fp16": 2e-3, "bf16": 5e-3}
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -163,8 +164,7 @@ def _run_vs_golden(mt, prec, golden_dir):
         slots = slots[torch.argsort(rank[slots])]
         same.append(np.array_equal(pos[slots].numpy(), fx[f"pp{b}_nms_index"]))
     print(f"[{mt}/{prec}] NMS index lists identical: {same}")
-    if prec == "fp16":
-        assert all(same)
+    assert all(same)
     return out
 
 

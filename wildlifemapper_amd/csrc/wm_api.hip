@@ -17,6 +17,7 @@
 #include "fft_kernels.h"
 #include "gemm16.h"
 #include "gemm16_v2.h"
+#include "gemm16_v3.h"
 #include "gemm32.h"
 #include "misc_kernels.h"
 #include "wm_common.h"
@@ -213,14 +214,33 @@ int launch_gemm16v2_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     return 0;
 }
 
-// fraction of the last round of 256 one-per-CU workgroups that is filled
-static double round_eff(long tiles) { return (double)tiles / (double)(((tiles + 255) / 256) * 256); }
+template <class T16, int BN, int WN>
+int launch_gemm16v3_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
+    using G = G3<BN, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v3_kernel<T16, BN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        attr_set = true;
+    }
+    const int grid = (a.M / 256) * (a.N / BN);
+    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
+               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
+    hipLaunchKernelGGL((gemm16v3_kernel<T16, BN, WN>), dim3(grid), dim3(G::THREADS), G::LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
-// WM_GEMM_MODE: 0 = auto, 1 = 128x128 kernel only (A/B testing)
+// fraction of the last round of workgroup slots that is filled
+static double round_eff(long tiles, long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); }
+
+// WM_GEMM_MODE (A/B runs): 0 = auto: 256x320 / 256x256 8-wave tiles (gemm16_v3.h), else 256x160/128 (gemm16_v2.h)
+//                          1 = 128x128 kernel only   2 = gemm16_v2.h only   3 = 4-wave 256x160/128 (two workgroups per CU)
 static int gemm_mode() {
     static const int m = getenv("WM_GEMM_MODE") ? atoi(getenv("WM_GEMM_MODE")) : 0;
     return m;
 }
+
+#define WM_BY_PREC(call_bf16, call_fp16) (prec == WM_PREC_FP16 ? (call_fp16) : (call_bf16))
 
 int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias,
                   const float* res, int res_mod, float* out32, void* out16, int M, int N, int K, int act) {
@@ -230,12 +250,21 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
     Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act};
     const int mode = gemm_mode();
     if (M % 256 == 0 && mode != 1) {
+        if (mode == 0) {
+            if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v3_t<BF16, 320, 4>(h, s, a)), (launch_gemm16v3_t<FP16, 320, 4>(h, s, a)));
+            if (N % 256 == 0) return WM_BY_PREC((launch_gemm16v3_t<BF16, 256, 4>(h, s, a)), (launch_gemm16v3_t<FP16, 256, 4>(h, s, a)));
+        }
+        const long slots = mode == 3 ? 512 : 256;
         const bool can160 = N % 160 == 0;
-        const bool use160 = can160 && round_eff((long)(M / 256) * (N / 160)) >= round_eff((long)(M / 256) * (N / 128)) - 1e-9;
-        if (use160) return prec == WM_PREC_FP16 ? launch_gemm16v2_t<FP16, 160>(h, s, a) : launch_gemm16v2_t<BF16, 160>(h, s, a);
-        return prec == WM_PREC_FP16 ? launch_gemm16v2_t<FP16, 128>(h, s, a) : launch_gemm16v2_t<BF16, 128>(h, s, a);
+        const bool use160 = can160 && round_eff((long)(M / 256) * (N / 160), slots) >= round_eff((long)(M / 256) * (N / 128), slots) - 1e-9;
+        if (mode == 3) {
+            if (use160) return WM_BY_PREC((launch_gemm16v3_t<BF16, 160, 2>(h, s, a)), (launch_gemm16v3_t<FP16, 160, 2>(h, s, a)));
+            return WM_BY_PREC((launch_gemm16v3_t<BF16, 128, 2>(h, s, a)), (launch_gemm16v3_t<FP16, 128, 2>(h, s, a)));
+        }
+        if (use160) return WM_BY_PREC((launch_gemm16v2_t<BF16, 160>(h, s, a)), (launch_gemm16v2_t<FP16, 160>(h, s, a)));
+        return WM_BY_PREC((launch_gemm16v2_t<BF16, 128>(h, s, a)), (launch_gemm16v2_t<FP16, 128>(h, s, a)));
     }
-    return prec == WM_PREC_FP16 ? launch_gemm16_t<FP16>(h, s, a) : launch_gemm16_t<BF16>(h, s, a);
+    return WM_BY_PREC((launch_gemm16_t<BF16>(h, s, a)), (launch_gemm16_t<FP16>(h, s, a)));
 }
 
 int launch_gemm32(wm_handle* h, hipStream_t s, const float* A, const float* W, const float* bias, const float* res,
@@ -459,9 +488,17 @@ void build_expected(wm_handle* h) {
     }
 }
 
+// Stem (patch / HFC embeds), HFC adaptor and neck always run with fp16 operands: they are 2.9 % of the FLOPs,
+// their inputs are normalised (|x| of a few units), and in bf16 they alone cost 1e-3 on the logits (DESIGN.md
+// "Precision").  The transformer blocks use the handle's precision (bf16 by default).
+bool is_stem_or_neck(const std::string& name) {
+    return name.rfind("image_encoder.patch_embed.", 0) == 0 || name.rfind("image_encoder.hfc_embed.", 0) == 0 ||
+           name.rfind("image_encoder.hfc_attn.", 0) == 0 || name.rfind("image_encoder.neck.", 0) == 0;
+}
+
 int upload16(wm_handle* h, const std::string& key, const float* src, size_t n) {
     std::vector<uint16_t> tmp(n);
-    if (h->prec == WM_PREC_FP16) for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_f16_host(src[i]);
+    if (h->prec == WM_PREC_FP16 || is_stem_or_neck(key)) for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_f16_host(src[i]);
     else for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16_host(src[i]);
     uint16_t* d = nullptr;
     WM_TRY(dalloc(h, &d, n * 2));
@@ -695,43 +732,39 @@ int fft_impl(wm_handle* h, const float* x, float* out, int B, hipStream_t s) {
 
 int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw, int B, hipStream_t s) {
     const int D = h->D, P = h->prec, M = B * T;
+    const int PS = WM_PREC_FP16;      // stem, HFC adaptor and neck: fp16 operands in every mode (see is_stem_or_neck)
     const std::string e = "image_encoder.", a = e + "hfc_attn.";
     // ---- stem: patch / HFC embeds (image_encoder.py:124-128) ----
-    if (P == WM_PREC_FP16) {
-        WM_TRY(launch_simple(h, s, B * 18.9e6, patchify_kernel<FP16>, dim3(grid_for((int64_t)B * 3 * 1024 * 256)), dim3(256), x, (u16*)h->p16, B, 3));
-        WM_TRY(launch_simple(h, s, B * 6.3e6, patchify_kernel<FP16>, dim3(grid_for((int64_t)B * 1024 * 256)), dim3(256), hfc, (u16*)h->h16, B, 1));
-    } else {
-        WM_TRY(launch_simple(h, s, B * 18.9e6, patchify_kernel<BF16>, dim3(grid_for((int64_t)B * 3 * 1024 * 256)), dim3(256), x, (u16*)h->p16, B, 3));
-        WM_TRY(launch_simple(h, s, B * 6.3e6, patchify_kernel<BF16>, dim3(grid_for((int64_t)B * 1024 * 256)), dim3(256), hfc, (u16*)h->h16, B, 1));
-    }
+    WM_TRY(launch_simple(h, s, B * 18.9e6, patchify_kernel<FP16>, dim3(grid_for((int64_t)B * 3 * 1024 * 256)), dim3(256), x, (u16*)h->p16, B, 3));
+    WM_TRY(launch_simple(h, s, B * 6.3e6, patchify_kernel<FP16>, dim3(grid_for((int64_t)B * 1024 * 256)), dim3(256), hfc, (u16*)h->h16, B, 1));
     // t = patch_embed(x) + pos_embed  -> tokbase (fp32) and xn16 (16-bit copy for proj_patch)
-    WM_TRY(launch_gemm16(h, s, P, h->p16, W16(h, e + "patch_embed.proj.weight"), W32(h, e + "patch_embed.proj.bias"),
+    WM_TRY(launch_gemm16(h, s, PS, h->p16, W16(h, e + "patch_embed.proj.weight"), W32(h, e + "patch_embed.proj.bias"),
                          W32(h, e + "pos_embed"), T, h->tokbase, h->xn16, M, D, 768, ACT_NONE));
-    WM_TRY(launch_gemm16(h, s, P, h->h16, W16(h, e + "hfc_embed.proj.weight"), W32(h, e + "hfc_embed.proj.bias"),
+    WM_TRY(launch_gemm16(h, s, PS, h->h16, W16(h, e + "hfc_embed.proj.weight"), W32(h, e + "hfc_embed.proj.bias"),
                          nullptr, 0, nullptr, h->he16, M, HFC, 256, ACT_NONE));
     // ---- HFC adaptor (image_encoder.py:486-516) ----
-    WM_TRY(launch_gemm16(h, s, P, h->he16, W16(h, a + "proj_hfc.weight"), W32(h, a + "proj_hfc.bias"),
+    WM_TRY(launch_gemm16(h, s, PS, h->he16, W16(h, a + "proj_hfc.weight"), W32(h, a + "proj_hfc.bias"),
                          W32(h, a + "pos_embed"), T, nullptr, h->hp16, M, HFC, HFC, ACT_NONE));                    // :494
-    WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, a + "proj_patch.weight"), W32(h, a + "proj_patch.bias"),
+    WM_TRY(launch_gemm16(h, s, PS, h->xn16, W16(h, a + "proj_patch.weight"), W32(h, a + "proj_patch.bias"),
                          nullptr, 0, h->pt32, h->pt16, M, HFC, D, ACT_NONE));                                       // :495
     const uint16_t* wi = W16(h, a + "cross_attn.in_proj_weight");
     const float* bi = W32(h, a + "cross_attn.in_proj_bias");
-    WM_TRY(launch_gemm16(h, s, P, h->pt16, wi, bi, nullptr, 0, nullptr, h->q16, M, HFC, HFC, ACT_NONE));
-    WM_TRY(launch_gemm16(h, s, P, h->hp16, wi + (size_t)HFC * HFC, bi + HFC, nullptr, 0, nullptr, h->kv16, M, 2 * HFC, HFC, ACT_NONE));
-    WM_TRY(launch_mha16(h, s, P, h->q16, HFC, h->kv16, 2 * HFC, h->kv16 + HFC, 2 * HFC, h->aoh16, HFC, B, HFC_HEADS,
+    WM_TRY(launch_gemm16(h, s, PS, h->pt16, wi, bi, nullptr, 0, nullptr, h->q16, M, HFC, HFC, ACT_NONE));
+    WM_TRY(launch_gemm16(h, s, PS, h->hp16, wi + (size_t)HFC * HFC, bi + HFC, nullptr, 0, nullptr, h->kv16, M, 2 * HFC, HFC, ACT_NONE));
+    WM_TRY(launch_mha16(h, s, PS, h->q16, HFC, h->kv16, 2 * HFC, h->kv16 + HFC, 2 * HFC, h->aoh16, HFC, B, HFC_HEADS,
                         HFC / HFC_HEADS, T, T));                                                                      // :500-503
-    WM_TRY(launch_gemm16(h, s, P, h->aoh16, W16(h, a + "cross_attn.out_proj.weight"), W32(h, a + "cross_attn.out_proj.bias"),
+    WM_TRY(launch_gemm16(h, s, PS, h->aoh16, W16(h, a + "cross_attn.out_proj.weight"), W32(h, a + "cross_attn.out_proj.bias"),
                          h->pt32, 0, h->y1, nullptr, M, HFC, HFC, ACT_NONE));                                       // + residual :504
-    WM_TRY(launch_layernorm(h, s, P, h->y1, W32(h, a + "norm1.weight"), W32(h, a + "norm1.bias"), 1e-5f, h->y1n32, h->y1n16, M, HFC));
-    WM_TRY(launch_gemm16(h, s, P, h->y1n16, W16(h, a + "linear1.weight"), W32(h, a + "linear1.bias"), nullptr, 0, nullptr,
+    WM_TRY(launch_layernorm(h, s, PS, h->y1, W32(h, a + "norm1.weight"), W32(h, a + "norm1.bias"), 1e-5f, h->y1n32, h->y1n16, M, HFC));
+    WM_TRY(launch_gemm16(h, s, PS, h->y1n16, W16(h, a + "linear1.weight"), W32(h, a + "linear1.bias"), nullptr, 0, nullptr,
                          h->h1_16, M, HFC, HFC, ACT_RELU));
-    WM_TRY(launch_gemm16(h, s, P, h->h1_16, W16(h, a + "linear2.weight"), W32(h, a + "linear2.bias"), h->y1n32, 0, h->z32,
+    WM_TRY(launch_gemm16(h, s, PS, h->h1_16, W16(h, a + "linear2.weight"), W32(h, a + "linear2.bias"), h->y1n32, 0, h->z32,
                          nullptr, M, HFC, HFC, ACT_NONE));                                                          // :506-508
-    WM_TRY(launch_layernorm(h, s, P, h->z32, W32(h, a + "norm2.weight"), W32(h, a + "norm2.bias"), 1e-5f, nullptr, h->y2_16, M, HFC));
+    WM_TRY(launch_layernorm(h, s, PS, h->z32, W32(h, a + "norm2.weight"), W32(h, a + "norm2.bias"), 1e-5f, nullptr, h->y2_16, M, HFC));
     // scramble (:512): per tile [4096 tok,1024 ch] re-read as [1024, 4096]; make it the K-contiguous A operand
     WM_TRY(launch_simple(h, s, B * 16.8e6, transpose16_kernel, dim3(T / 64, HFC / 64, B), dim3(256), (const u16*)h->y2_16, (u16*)h->y2t16, HFC, T));
     // x = proj_back(scrambled) + t   (:513-514, :131)
-    WM_TRY(launch_gemm16(h, s, P, h->y2t16, W16(h, a + "proj_back.weight"), W32(h, a + "proj_back.bias"), h->tokbase, 0,
+    WM_TRY(launch_gemm16(h, s, PS, h->y2t16, W16(h, a + "proj_back.weight"), W32(h, a + "proj_back.bias"), h->tokbase, 0,
                          h->resid, nullptr, M, D, HFC, ACT_NONE));
     WM_TRY(do_tap(h, s, -1, B));
 
@@ -748,19 +781,19 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
         WM_TRY(launch_layernorm(h, s, P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, nullptr, h->xn16, M, D));
         WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.bias"), nullptr, 0, nullptr,
                              h->hid16, M, 4 * D, D, ACT_GELU));
-        const bool last = i == h->depth - 1;
         WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
-                             h->resid, last ? h->x16last : nullptr, M, D, 4 * D, ACT_NONE));
+                             h->resid, nullptr, M, D, 4 * D, ACT_NONE));
         WM_TRY(do_tap(h, s, i, B));
     }
 
     // ---- neck (image_encoder.py:105-121,136) ----
-    WM_TRY(launch_gemm16(h, s, P, h->x16last, W16(h, e + "neck.0.weight"), nullptr, nullptr, 0, h->n1, nullptr, M, OUTC, D, ACT_NONE));
-    WM_TRY(launch_layernorm(h, s, P, h->n1, W32(h, e + "neck.1.weight"), W32(h, e + "neck.1.bias"), 1e-6f, nullptr, h->n1n16, M, OUTC));
+    WM_TRY(launch_simple(h, s, B * 31.5e6, cvt_f32_to_16_kernel<FP16>, dim3(grid_for((int64_t)M * D / 4)), dim3(256), (const float*)h->resid, (u16*)h->x16last, (int64_t)M * D / 4));
+    WM_TRY(launch_gemm16(h, s, PS, h->x16last, W16(h, e + "neck.0.weight"), nullptr, nullptr, 0, h->n1, nullptr, M, OUTC, D, ACT_NONE));
+    WM_TRY(launch_layernorm(h, s, PS, h->n1, W32(h, e + "neck.1.weight"), W32(h, e + "neck.1.bias"), 1e-6f, nullptr, h->n1n16, M, OUTC));
     WM_TRY(launch_simple(h, s, B * 21e6, im2col3x3_kernel, dim3(grid_for((int64_t)M * 9 * (OUTC / 8))), dim3(256), (const u16*)h->n1n16,
                          (u16*)h->col16, B, OUTC));
-    WM_TRY(launch_gemm16(h, s, P, h->col16, W16(h, e + "neck.2.weight"), nullptr, nullptr, 0, h->n2, nullptr, M, OUTC, 9 * OUTC, ACT_NONE));
-    WM_TRY(launch_layernorm(h, s, P, h->n2, W32(h, e + "neck.3.weight"), W32(h, e + "neck.3.bias"), 1e-6f, h->emb_nhwc, nullptr, M, OUTC));
+    WM_TRY(launch_gemm16(h, s, PS, h->col16, W16(h, e + "neck.2.weight"), nullptr, nullptr, 0, h->n2, nullptr, M, OUTC, 9 * OUTC, ACT_NONE));
+    WM_TRY(launch_layernorm(h, s, PS, h->n2, W32(h, e + "neck.3.weight"), W32(h, e + "neck.3.bias"), 1e-6f, h->emb_nhwc, nullptr, M, OUTC));
     if (out_nchw)
         WM_TRY(launch_simple(h, s, B * 8.4e6, transpose32_kernel, dim3(OUTC / 64, T / 64, B), dim3(256), (const float*)h->emb_nhwc, out_nchw, T, OUTC));
     return 0;
