@@ -138,8 +138,15 @@ def main() -> None:
         g = st["gemm16"]
         achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         peak = PEAK_TFLOPS[a.precision if a.precision in PEAK_TFLOPS else "bf16"]
+        traffic = None
+        try:   # HBM bytes per GEMM launch from the PMC passes committed under profiles/ (collected offline with rocprofv3)
+            with open(os.path.join(ROOT, "profiles", "r1c_pmc_traffic.json")) as f:
+                traffic = json.load(f)["classes"]["gemm16"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "mfma", "kernel": "gemm16v2_kernel<T,160|128> (all 16-bit MFMA GEMM launches)", "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1c_pmc_traffic.json (B=4 run)",
                     "launches_per_step": g["launches"] // a.steps,
                     "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
                     "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),

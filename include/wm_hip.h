@@ -31,9 +31,11 @@ extern "C" {
 
 #define WM_ABI_VERSION 1
 
-/* operand type of the MFMA GEMM / attention path (accumulation is fp32) */
+/* operand type of the transformer blocks' MFMA GEMMs / attention (accumulation, residual stream, LayerNorm
+ * statistics, softmax and the whole decoder are fp32; the stem, the HFC adaptor and the neck -- 2.9 % of the
+ * FLOPs -- always use fp16 operands, see DESIGN.md "Precision") */
 #define WM_PREC_BF16 0   /* north_star default: bf16 MFMA                         */
-#define WM_PREC_FP16 1   /* fp16 MFMA, same rate, 3 more mantissa bits (DESIGN.md) */
+#define WM_PREC_FP16 1   /* fp16 MFMA, same rate, 3 more mantissa bits */
 
 #define WM_MAX_GLOBAL 8
 #define WM_NUM_QUERIES 51   /* segment_anything/modeling/box_decoder.py:53 (50 + 1) */
@@ -163,6 +165,12 @@ int wm_op_cvt_16_to_f32(const void* in_dev, float* out_dev, int64_t n, int preci
 int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* bias_dev,
                  const float* residual_dev, int res_mod, float* out_f32_dev, void* out_16_dev,
                  int M, int N, int K, int act, int precision, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution without bias over a 64x64 token grid as an implicit GEMM (no im2col
+ * buffer): the second neck conv, image_encoder.py:113-119.  a [B,64,64,c_in] NHWC 16-bit,
+ * w [c_out][ky*3+kx][c_in] 16-bit (packed tap-major), out [B*4096, c_out] fp32.  c_out % 256 == 0, c_in % 32 == 0. */
+int wm_op_conv3x3_16(const void* a_dev, const void* w_dev, float* out_dev, int batch, int c_out, int c_in,
+                     int precision, void* stream);
 
 /* fp32 GEMM on the fp32-input MFMA, same contract (act 3 = sigmoid). */
 int wm_op_gemm32(const float* a_dev, const float* w_dev, const float* bias_dev,

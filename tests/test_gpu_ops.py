@@ -97,6 +97,23 @@ def test_gemm16_rejects_ragged():
         G.gemm16(a, w)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_conv3x3_implicit_gemm(prec):
+    """Neck 3x3 conv (image_encoder.py:113-119) without an im2col buffer, against F.conv2d on the rounded operands."""
+    B, Cin, Cout, dev = 2, 256, 256, G.dev()
+    x = G.to16(torch.randn(B, 64, 64, Cin, device=dev), prec)                       # NHWC
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) / math.sqrt(9 * Cin)
+    w16 = G.to16(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous(), prec)   # [co][tap][ci]
+    out = torch.empty(B * 4096, Cout, device=dev)
+    from wildlifemapper_amd import _native as Nn
+    Nn.check(Nn.lib().wm_op_conv3x3_16(Nn.ptr(x), Nn.ptr(w16), Nn.ptr(out), B, Cout, Cin, G.PRECS[prec][0], G.sp()))
+    wr = w16.float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), wr, padding=1).permute(0, 2, 3, 1).reshape(B * 4096, Cout)
+    assert G.rel_l2(out, ref) < 1e-5
+    # borders: the corner pixel sees only 4 taps
+    assert torch.allclose(out[0], ref[0], rtol=1e-4, atol=1e-5) and torch.allclose(out[4095], ref[4095], rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("M,N,K,act", [(51, 8, 256, 0), (102, 4, 256, 3), (4096, 128, 256, 0), (51, 2048, 256, 2), (153, 256, 2048, 0), (64, 64, 16, 1)])
 def test_gemm32(M, N, K, act):
     a = torch.randn(M, K, device=G.dev())

@@ -55,6 +55,7 @@ SYMBOLS = {
     "wm_op_cvt_f32_to_16": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_cvt_16_to_f32": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_gemm16": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm_op_conv3x3_16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "wm_op_gemm32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "wm_op_layernorm": (_I, [_P, _P, _P, _F, _P, _P, _L, _I, _I, _P]),
     "wm_op_encoder_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -39,6 +39,11 @@ struct Gemm16Args {
     int M, N, K;
     int res_mod;             // rows of residual (M, or 4096 for a per-tile broadcast)
     int act;
+    // implicit-GEMM A operand (gemm16_v3.h, AMODE 1): A is an NHWC activation [M = B*64*64, conv_c] and the
+    // GEMM's K runs over (tap, channel) of a 3x3 / pad 1 convolution, K = 9 * conv_c; out-of-image taps read
+    // `zero_page` (>= 64 B of zeros).  Unused (0 / null) for a plain A matrix.
+    int conv_c;
+    const u16* zero_page;
 };
 
 template <class T>

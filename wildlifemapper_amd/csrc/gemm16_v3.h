@@ -18,6 +18,9 @@
 //   K-step 32: LDS rows are 64 B; 3-slot ring of (256 + BN) x 64 B (108 KiB at BN = 320).
 //   DMA piece = 16 rows x 64 B; swizzle phys_chunk = chunk ^ ((-(row >> 2)) & 3) on the SOURCE address and
 //   on the ds_read_b128 address (conflict-free lane groups).
+//   AMODE 1 (im2col-free 3x3 conv, the neck's second conv image_encoder.py:113-119): the A tile of K-step s
+//   is the 32-channel slice ci0 = (32 s) % C of tap (32 s) / C of the NHWC activation, shifted by the tap's
+//   (dy, dx); the DMA source address is computed per lane and points at a zero page outside the image.
 //   W pieces do not divide evenly over the waves: waves < W_REM issue one more, and wait with their own
 //   counted vmcnt.  Synchronisation as gemm16_v2.h (counted vmcnt + raw s_barrier, DMA of step s+2 after the
 //   barrier, spread between the MFMAs).
@@ -53,7 +56,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <class T, int BN, int WN>
+template <class T, int BN, int WN, int AMODE = 0>
 __global__ __launch_bounds__((G3<BN, WN>::THREADS), 2) void gemm16v3_kernel(Gemm16Args p) {
     using C = G3<BN, WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -87,9 +90,23 @@ __global__ __launch_bounds__((G3<BN, WN>::THREADS), 2) void gemm16v3_kernel(Gemm
     const size_t row_bytes = (size_t)K * 2;
     auto dma_a = [&](int slot, int s, int i) {
         const int seg = wave * C::A_PIECES + i;
-        const char* base = Ab + (size_t)(m0 + seg * 16) * row_bytes + (size_t)s * 64;
-        if (dbg_nodma) base = Ab;
-        __builtin_amdgcn_global_load_lds(base + (dbg_nodma ? (lane_off & 1023u) : lane_off), WM_LDS_PTR(smem + slot * C::STAGE + seg * 1024), 16, 0, 0);
+        if constexpr (AMODE == 0) {
+            const char* base = Ab + (size_t)(m0 + seg * 16) * row_bytes + (size_t)s * 64;
+            if (dbg_nodma) base = Ab;
+            __builtin_amdgcn_global_load_lds(base + (dbg_nodma ? (lane_off & 1023u) : lane_off), WM_LDS_PTR(smem + slot * C::STAGE + seg * 1024), 16, 0, 0);
+        } else {
+            // pixel of this lane's row; 16 consecutive rows of a piece lie in one image row (64 % 16 == 0)
+            const int m = m0 + seg * 16 + (lane >> 2);
+            const int pix = m & 4095, y = pix >> 6, x = pix & 63;
+            const int kg = s * 32, tap = kg / p.conv_c, ci0 = kg - tap * p.conv_c;     // wave-uniform
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const int yy = y + dy, xx = x + dx;
+            const unsigned chunk_off = (unsigned)((((lane & 3) ^ ((0 - (lane >> 4)) & 3))) << 4);
+            const bool inside = (unsigned)yy < 64u && (unsigned)xx < 64u;
+            const char* src = inside ? Ab + ((size_t)(m + dy * 64 + dx) * p.conv_c + ci0) * 2 + chunk_off
+                                     : (const char*)p.zero_page + chunk_off;
+            __builtin_amdgcn_global_load_lds(src, WM_LDS_PTR(smem + slot * C::STAGE + seg * 1024), 16, 0, 0);
+        }
     };
     auto dma_w = [&](int slot, int s, int seg) {
         const char* base = Wb + (size_t)(n0 + seg * 16) * row_bytes + (size_t)s * 64;

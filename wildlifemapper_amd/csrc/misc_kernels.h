@@ -149,22 +149,4 @@ __global__ __launch_bounds__(256) void cvt_16_to_f32_kernel(const u16* __restric
     }
 }
 
-// im2col for the neck 3x3 conv (image_encoder.py:113-119): in [B,64,64,C] 16-bit NHWC ->
-// out [B*4096, 9*C], column = tap*C + ci, tap = ky*3+kx, zero outside the grid (padding=1).
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const u16* __restrict__ in, u16* __restrict__ out, int B, int C) {
-    const int chunks = C / 8;                                   // 16-byte chunks per pixel
-    const int64_t total = (int64_t)B * 4096 * 9 * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int ch = (int)(i % chunks);
-        const int tap = (int)((i / chunks) % 9);
-        const int64_t pixg = i / (chunks * 9);
-        const int pix = (int)(pixg & 4095);
-        const int64_t b = pixg >> 12;
-        const int y = (pix >> 6) + tap / 3 - 1, x = (pix & 63) + tap % 3 - 1;
-        s16x8 v = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (y >= 0 && y < 64 && x >= 0 && x < 64) v = *(const s16x8*)(in + ((b * 4096 + y * 64 + x) * C) + ch * 8);
-        *(s16x8*)(out + pixg * (9 * C) + tap * C + ch * 8) = v;
-    }
-}
-
 }  // namespace wm

@@ -125,7 +125,7 @@ struct wm_handle {
              *kv16 = nullptr, *aoh16 = nullptr, *y1n16 = nullptr, *h1_16 = nullptr, *y2_16 = nullptr, *y2t16 = nullptr;
     float *pt32 = nullptr, *y1 = nullptr, *y1n32 = nullptr, *z32 = nullptr;
     float *n1 = nullptr, *n2 = nullptr, *emb_nhwc = nullptr, *emb_nchw = nullptr;
-    uint16_t *n1n16 = nullptr, *col16 = nullptr, *x16last = nullptr;
+    uint16_t *n1n16 = nullptr, *x16last = nullptr;
     float *dkeys = nullptr, *dk_a = nullptr, *dk_b = nullptr, *dk_c = nullptr;      // [B*T,256],[B*T,128] x3
     float *dq = nullptr, *dt_q = nullptr, *dt_k = nullptr, *dt_v = nullptr, *dt_att = nullptr, *dt_hid = nullptr,
           *dt_h1 = nullptr, *dt_h2 = nullptr;
@@ -247,7 +247,7 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
     if (M <= 0 || N <= 0 || K <= 0 || M % G16_BM || N % G16_BN || K % G16_BK)
         return fail("gemm16: shape M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, G16_BM, G16_BN, G16_BK);
     if (!out32 && !out16) return fail("gemm16: no output");
-    Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act};
+    Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act, 0, nullptr};
     const int mode = gemm_mode();
     if (M % 256 == 0 && mode != 1) {
         if (mode == 0) {
@@ -265,6 +265,30 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
         return WM_BY_PREC((launch_gemm16v2_t<BF16, 128>(h, s, a)), (launch_gemm16v2_t<FP16, 128>(h, s, a)));
     }
     return WM_BY_PREC((launch_gemm16_t<BF16>(h, s, a)), (launch_gemm16_t<FP16>(h, s, a)));
+}
+
+// 3x3 / pad 1 convolution over an NHWC [B,64,64,C] 16-bit activation as an implicit GEMM (no im2col buffer):
+// out[M = B*4096, N] = conv(A) with W packed [N][tap][C]  (image_encoder.py:113-119)
+int launch_conv3x3_16(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, float* out32, int M, int N, int Cin) {
+    if (M % 4096 || N % 256 || Cin % 32) return fail("conv3x3: M=%d N=%d C=%d unsupported (M %% 4096, N %% 256, C %% 32)", M, N, Cin);
+    static uint16_t* zero_page = nullptr;      // 256 B of zeros for out-of-image taps (one per process)
+    if (!zero_page) {
+        HIP_TRY(hipMalloc((void**)&zero_page, 256));
+        HIP_TRY(hipMemset(zero_page, 0, 256));
+    }
+    Gemm16Args a{(const u16*)A, (const u16*)W, nullptr, nullptr, out32, nullptr, M, N, 9 * Cin, 0, ACT_NONE, Cin, (const u16*)zero_page};
+    using G = G3<256, 4>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v3_kernel<FP16, 256, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v3_kernel<BF16, 256, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        attr_set = true;
+    }
+    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * M * (double)N * 9 * Cin, 2.0 * ((double)M * Cin + 9.0 * N * Cin) + 4.0 * M * N);
+    if (prec == WM_PREC_FP16) hipLaunchKernelGGL((gemm16v3_kernel<FP16, 256, 4, 1>), dim3((M / 256) * (N / 256)), dim3(G::THREADS), G::LDS, s, a);
+    else hipLaunchKernelGGL((gemm16v3_kernel<BF16, 256, 4, 1>), dim3((M / 256) * (N / 256)), dim3(G::THREADS), G::LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int launch_gemm32(wm_handle* h, hipStream_t s, const float* A, const float* W, const float* bias, const float* res,
@@ -557,7 +581,7 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     A(y2_16, BT * HFC * 2); A(y2t16, BT * HFC * 2);
     A(pt32, BT * HFC * 4); A(y1, BT * HFC * 4); A(y1n32, BT * HFC * 4); A(z32, BT * HFC * 4);
     A(n1, BT * OUTC * 4); A(n2, BT * OUTC * 4); A(emb_nhwc, BT * OUTC * 4); A(emb_nchw, BT * OUTC * 4);
-    A(n1n16, BT * OUTC * 2); A(col16, BT * 9 * OUTC * 2); A(x16last, BT * D * 2);
+    A(n1n16, BT * OUTC * 2); A(x16last, BT * D * 2);
     A(dkeys, BT * OUTC * 4); A(dk_a, BT * 128 * 4); A(dk_b, BT * 128 * 4); A(dk_c, BT * 128 * 4);
     A(dq, B * NQ * OUTC * 4); A(dt_q, B * NQ * OUTC * 4); A(dt_k, B * NQ * OUTC * 4); A(dt_v, B * NQ * OUTC * 4);
     A(dt_att, B * NQ * OUTC * 4); A(dt_hid, B * NQ * DEC_MLP * 4); A(dt_h1, B * NQ * OUTC * 4); A(dt_h2, B * NQ * OUTC * 4);
@@ -790,9 +814,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     WM_TRY(launch_simple(h, s, B * 31.5e6, cvt_f32_to_16_kernel<FP16>, dim3(grid_for((int64_t)M * D / 4)), dim3(256), (const float*)h->resid, (u16*)h->x16last, (int64_t)M * D / 4));
     WM_TRY(launch_gemm16(h, s, PS, h->x16last, W16(h, e + "neck.0.weight"), nullptr, nullptr, 0, h->n1, nullptr, M, OUTC, D, ACT_NONE));
     WM_TRY(launch_layernorm(h, s, PS, h->n1, W32(h, e + "neck.1.weight"), W32(h, e + "neck.1.bias"), 1e-6f, nullptr, h->n1n16, M, OUTC));
-    WM_TRY(launch_simple(h, s, B * 21e6, im2col3x3_kernel, dim3(grid_for((int64_t)M * 9 * (OUTC / 8))), dim3(256), (const u16*)h->n1n16,
-                         (u16*)h->col16, B, OUTC));
-    WM_TRY(launch_gemm16(h, s, PS, h->col16, W16(h, e + "neck.2.weight"), nullptr, nullptr, 0, h->n2, nullptr, M, OUTC, 9 * OUTC, ACT_NONE));
+    WM_TRY(launch_conv3x3_16(h, s, PS, h->n1n16, W16(h, e + "neck.2.weight"), h->n2, M, OUTC, OUTC));
     WM_TRY(launch_layernorm(h, s, PS, h->n2, W32(h, e + "neck.3.weight"), W32(h, e + "neck.3.bias"), 1e-6f, h->emb_nhwc, nullptr, M, OUTC));
     if (out_nchw)
         WM_TRY(launch_simple(h, s, B * 8.4e6, transpose32_kernel, dim3(OUTC / 64, T / 64, B), dim3(256), (const float*)h->emb_nhwc, out_nchw, T, OUTC));
@@ -1018,6 +1040,11 @@ extern "C" int wm_op_cvt_16_to_f32(const void* in_dev, float* out_dev, int64_t n
 extern "C" int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev, int res_mod,
                             float* out_f32_dev, void* out_16_dev, int M, int N, int K, int act, int precision, void* stream) {
     return launch_gemm16(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, bias_dev, residual_dev, res_mod, out_f32_dev, out_16_dev, M, N, K, act);
+}
+
+extern "C" int wm_op_conv3x3_16(const void* a_dev, const void* w_dev, float* out_dev, int batch, int c_out, int c_in, int precision,
+                               void* stream) {
+    return launch_conv3x3_16(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, out_dev, batch * 4096, c_out, c_in);
 }
 
 extern "C" int wm_op_gemm32(const float* a_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* out_dev,
