@@ -73,9 +73,13 @@ def main() -> None:
     ap.add_argument("--workload", default="full", choices=["full", "encoder"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL, default) | gloo (single-GPU rehearsal of the N>1 path)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     a = ap.parse_args()
 
-    rank, world, local = wdist.init_from_env("nccl")
+    rank, world, local = wdist.init_from_env(a.backend)
+    if a.same_device:
+        local = 0
     if world != a.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -116,7 +120,7 @@ def main() -> None:
             step()
         sync()
         elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    tmax = torch.tensor([elapsed], device=device if a.backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
@@ -124,36 +128,44 @@ def main() -> None:
 
     roofline = None
     classes = None
-    if not a.no_roofline and rank == 0:
-        hub.profile_enable(True)
-        hub.profile_reset()
+    if not a.no_roofline:
+        # second pass of the same steps with per-kernel HIP events on rank 0; every rank runs the steps because
+        # a step of the N > 1 path contains the all-gather
+        if rank == 0:
+            hub.profile_enable(True)
+            hub.profile_reset()
         with torch.no_grad():
+            sync()
             t1 = time.perf_counter()
             for _ in range(a.steps):
                 step()
             torch.cuda.synchronize(device)
             prof_elapsed = time.perf_counter() - t1
-        st = hub.profile_read()
-        hub.profile_enable(False)
-        g = st["gemm16"]
-        achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        peak = PEAK_TFLOPS[a.precision if a.precision in PEAK_TFLOPS else "bf16"]
-        traffic = None
-        try:   # HBM bytes per GEMM launch from the PMC passes committed under profiles/ (collected offline with rocprofv3)
-            with open(os.path.join(ROOT, "profiles", "r1c_pmc_traffic.json")) as f:
-                traffic = json.load(f)["classes"]["gemm16"]["hbm_bytes_per_launch"]
-        except Exception:
+        if rank == 0:
+            st = hub.profile_read()
+            hub.profile_enable(False)
+            g = st["gemm16"]
+            achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+            peak = PEAK_TFLOPS[a.precision if a.precision in PEAK_TFLOPS else "bf16"]
             traffic = None
-        roofline = {"bound": "mfma", "kernel": "gemm16v2_kernel<T,160|128> (all 16-bit MFMA GEMM launches)", "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1c_pmc_traffic.json (B=4 run)",
-                    "launches_per_step": g["launches"] // a.steps,
-                    "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
-                    "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
-                    "ms_per_step_with_events": round(prof_elapsed / a.steps * 1e3, 3)}
-        classes = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["launches"] // a.steps,
-                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
-                   for k, v in st.items()}
+            try:   # HBM bytes per GEMM launch from the PMC passes committed under profiles/ (collected offline with rocprofv3)
+                with open(os.path.join(ROOT, "profiles", "r1c_pmc_traffic.json")) as f:
+                    traffic = json.load(f)["classes"]["gemm16"]["hbm_bytes_per_launch"]
+                if a.model != "vit_h" or B != 4:
+                    traffic = None          # the committed counters are for the default workload only
+            except Exception:
+                traffic = None
+            roofline = {"bound": "mfma", "kernel": "gemm16v3_kernel<T,320|256,4> (all 16-bit MFMA GEMM launches)",
+                        "achieved": round(achieved, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                        "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1c_pmc_traffic.json (B=4 run)",
+                        "launches_per_step": g["launches"] // a.steps,
+                        "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
+                        "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
+                        "ms_per_step_with_events": round(prof_elapsed / a.steps * 1e3, 3)}
+            classes = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["launches"] // a.steps,
+                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
+                       for k, v in st.items()}
     if world > 1:
         dist.barrier()
 
@@ -166,7 +178,7 @@ def main() -> None:
             "config": {"workload": (f"{a.model} {'encoder only' if a.workload == 'encoder' else 'full path fft+encoder+decoder+PostProcess/NMS'}"
                                     f", {a.precision} MFMA, batch={B} tiles/GPU of 1024x1024x3 (BASELINE.json configs[1] batch"
                                     f"{'' if a.workload == 'encoder' else ', configs[2]/[3] scope'})"),
-                       "tiles_per_step": n_tiles, "parallelism": f"dp{world} tile shard" + (", RCCL all-gather of box records" if world > 1 and a.workload == "full" else ""),
+                       "tiles_per_step": n_tiles, "parallelism": f"dp{world} tile shard" + (f", {'RCCL' if a.backend == 'nccl' else a.backend} all-gather of box records" if world > 1 and a.workload == "full" else ""),
                        "weights": "seed 0 synthetic (random init)"},
             "model_tflops": round(tiles_per_s * flops_tile / 1e12, 1) if flops_tile else None,
             "frac_of_mfma_peak_whole_path": round(tiles_per_s * flops_tile / 1e12 / (PEAK_TFLOPS.get(a.precision, 2500.0) * world), 4) if flops_tile else None,

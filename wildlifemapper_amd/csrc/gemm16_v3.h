@@ -153,10 +153,12 @@ __global__ __launch_bounds__((G3<BN, WN>::THREADS), 2) void gemm16v3_kernel(Gemm
         if constexpr (DMA) stage_extra(nsl, dma_s);                  // own basic block, ahead of the scheduled region
         const char* sS = smem + slot * C::STAGE;
         typename T::vec8 wf[C::NT], af[C::MT];
+        // issue order A0, W0..W(NT-1), A1..: the first MFMA needs only the first two reads back
+        af[0] = *(const typename T::vec8*)(sS + rd_a);
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) wf[i] = *(const typename T::vec8*)(sS + rd_w + i * 1024);
 #pragma unroll
-        for (int i = 0; i < C::MT; ++i) af[i] = *(const typename T::vec8*)(sS + rd_a + i * 1024);
+        for (int i = 1; i < C::MT; ++i) af[i] = *(const typename T::vec8*)(sS + rd_a + i * 1024);
         if constexpr (DMA) stage_uniform(nsl, dma_s);
 #pragma unroll
         for (int mi = 0; mi < C::MT; ++mi)

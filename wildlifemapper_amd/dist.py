@@ -51,10 +51,14 @@ def all_gather_records(records: torch.Tensor, n_tiles: int, rank: int, world: in
     if world == 1:
         return records
     cap = max_shard(n_tiles, world)
-    padded = torch.zeros((cap, SLOTS, RECORD_FLOATS), dtype=torch.float32, device=records.device)
-    padded[: records.shape[0]] = records
-    out = torch.empty((world, cap, SLOTS, RECORD_FLOATS), dtype=torch.float32, device=records.device)
+    # RCCL gathers device buffers directly; the gloo backend (CPU tests, single-GPU rehearsals) needs host memory
+    home = records.device
+    work = torch.device("cpu") if (dist.get_backend() == "gloo" and records.is_cuda) else home
+    padded = torch.zeros((cap, SLOTS, RECORD_FLOATS), dtype=torch.float32, device=work)
+    padded[: records.shape[0]] = records.to(work)
+    out = torch.empty((world, cap, SLOTS, RECORD_FLOATS), dtype=torch.float32, device=work)
     dist.all_gather_into_tensor(out.view(-1), padded.view(-1))
+    out = out.to(home)
     parts: List[torch.Tensor] = []
     for r in range(world):
         s, e = shard_range(n_tiles, r, world)
