@@ -380,20 +380,15 @@ template <int HD> struct WindowLds {
 };
 
 template <class T, int HD>
-__global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p) {
+__global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nitems) {
     using G = AttnGeom<HD>;
     using L = WindowLds<HD>;
     constexpr int WS = 14, GRID = 64, NWIN = 5, NTOK = WS * WS, NTHR = 448;
+    constexpr int NPF = (L::NKEY * G::CH) / NTHR;                // 16-byte K (and V) chunks per thread per item
+    static_assert((L::NKEY * G::CH) % NTHR == 0, "staging split");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    // 1-D grid, XCD-remapped so that the heads of one window (which read the same qkv rows) are
-    // neighbours on one XCD / one L2
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int head = lid % p.heads;
-    const int win = (lid / p.heads) % (NWIN * NWIN);
-    const int b = lid / (p.heads * NWIN * NWIN);
-    const int wy = win / NWIN, wx = win % NWIN;
     const int D = p.heads * HD;
     const float c1 = p.scale * 1.44269504088896340736f;
     const float inv_scale = 1.0f / p.scale;
@@ -403,33 +398,80 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p) {
     char* sTab = smem + L::TAB_OFF;
     float* sT = (float*)(smem + L::T_OFF) + wave * (32 * 65);
 
-    const u16* base = p.q + ((size_t)b * GRID * GRID) * p.q_stride + head * HD;   // packed qkv: q at +0, k at +D, v at +2D
+    // Persistent: one workgroup per CU walks items (tile, window, head).  All 196 keys of a window live in
+    // LDS (one workgroup per CU), so nothing else on the CU could hide the latency of staging them: the next
+    // item's K / V chunks and Q fragments are fetched into registers while the current item computes.
+    // Item order: heads of one window are neighbours and, through the XCD remap, share an L2.
+    auto decode = [&](int item, int& b, int& win, int& head) {
+        head = item % p.heads;
+        win = (item / p.heads) % (NWIN * NWIN);
+        b = item / (p.heads * NWIN * NWIN);
+    };
 
-    // ---- stage K, V (all 224 rows; rows >= 196 zero) and the two rel-pos tables ----
-    for (int e = tid; e < L::NKEY * G::CH; e += NTHR) {
-        const int key = e / G::CH, ch = e % G::CH;
-        s16x8 kv8 = s16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv8 = kv8;
-        if (key < NTOK) {
-            const int y = wy * WS + key / WS, x = wx * WS + key % WS;
-            if (y < GRID && x < GRID) {
-                const u16* row = base + (size_t)(y * GRID + x) * p.q_stride;
-                kv8 = *(const s16x8*)(row + D + ch * 8);
-                vv8 = *(const s16x8*)(row + 2 * D + ch * 8);
-            } else {
-                // zero-padded token after norm1 -> qkv = bias (image_encoder.py:190-194, 281)
-                typename T::vec8 tk, tv;
+    s16x8 kreg[NPF], vreg[NPF];
+    auto prefetch_kv = [&](int item) {
+        int b, win, head;
+        decode(item, b, win, head);
+        const int wy = win / NWIN, wx = win % NWIN;
+        const u16* base = p.q + ((size_t)b * GRID * GRID) * p.q_stride + head * HD;   // packed qkv: q +0, k +D, v +2D
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    tk[j] = T::from_f32(p.qkv_bias[D + head * HD + ch * 8 + j]);
-                    tv[j] = T::from_f32(p.qkv_bias[2 * D + head * HD + ch * 8 + j]);
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + i * NTHR;
+            const int key = e / G::CH, ch = e % G::CH;
+            s16x8 kv8 = s16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv8 = kv8;                      // rows >= 196 stay zero
+            if (key < NTOK) {
+                const int y = wy * WS + key / WS, x = wx * WS + key % WS;
+                if (y < GRID && x < GRID) {
+                    const u16* row = base + (size_t)(y * GRID + x) * p.q_stride;
+                    kv8 = *(const s16x8*)(row + D + ch * 8);
+                    vv8 = *(const s16x8*)(row + 2 * D + ch * 8);
+                } else {
+                    // zero-padded token after norm1 -> qkv = bias (image_encoder.py:190-194, 281)
+                    typename T::vec8 tk, tv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        tk[j] = T::from_f32(p.qkv_bias[D + head * HD + ch * 8 + j]);
+                        tv[j] = T::from_f32(p.qkv_bias[2 * D + head * HD + ch * 8 + j]);
+                    }
+                    kv8 = __builtin_bit_cast(s16x8, tk);
+                    vv8 = __builtin_bit_cast(s16x8, tv);
                 }
-                kv8 = __builtin_bit_cast(s16x8, tk);
-                vv8 = __builtin_bit_cast(s16x8, tv);
             }
+            kreg[i] = kv8;
+            vreg[i] = vv8;
         }
-        *(s16x8*)(sK + key * G::KS + ch * 16) = kv8;
-        *(s16x8*)(sV + key * G::VS + ch * 16) = vv8;
-    }
+    };
+    auto commit_kv = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + i * NTHR;
+            const int key = e / G::CH, ch = e % G::CH;
+            *(s16x8*)(sK + key * G::KS + ch * 16) = kreg[i];
+            *(s16x8*)(sV + key * G::VS + ch * 16) = vreg[i];
+        }
+    };
+    // this wave's 32 query slots of an item: validity, token, Q fragments
+    const int qi = wave * 32 + c;                         // slot in the window (0..223)
+    const int qh = qi / WS, qw = qi - qh * WS;
+    struct QInfo { bool valid; size_t row; };
+    auto q_info = [&](int item) {
+        int b, win, head;
+        decode(item, b, win, head);
+        const int y = (win / NWIN) * WS + qh, x = (win % NWIN) * WS + qw;
+        const bool valid = (qi < NTOK) && (y < GRID) && (x < GRID);
+        const size_t tok = valid ? (size_t)(y * GRID + x) : 0;
+        return QInfo{valid, (size_t)b * GRID * GRID + tok};
+    };
+    auto load_q = [&](typename T::vec8 (&qf)[G::NKS], int item) {
+        int b, win, head;
+        decode(item, b, win, head);
+        const QInfo qi_ = q_info(item);
+        const u16* src = p.q + qi_.row * p.q_stride + head * HD;
+#pragma unroll
+        for (int ks = 0; ks < G::NKS; ++ks) qf[ks] = *(const typename T::vec8*)(src + 16 * ks + 8 * h);
+    };
+
+    // rel-pos tables: the same for every item of this launch
     for (int e = tid; e < 64 * (HD / 4); e += NTHR) {
         const int row = e / (HD / 4), c4 = e % (HD / 4);
         const int tr = row & 31;
@@ -441,60 +483,76 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p) {
         *(typename T::vec4*)(sTab + row * G::KS + c4 * 8) = o;
     }
 
-    // this wave's 32 query slots
-    const int qi = wave * 32 + c;                         // slot in the window (0..223)
-    const int qh = qi / WS, qw = qi - qh * WS;
-    const int y = wy * WS + qh, x = wx * WS + qw;
-    const bool qvalid = (qi < NTOK) && (y < GRID) && (x < GRID);
-    const size_t tok = qvalid ? (size_t)(y * GRID + x) : 0;
-    typename T::vec8 qf[G::NKS];
-#pragma unroll
-    for (int ks = 0; ks < G::NKS; ++ks)
-        qf[ks] = *(const typename T::vec8*)(base + tok * p.q_stride + 16 * ks + 8 * h);
+    const int Gd = gridDim.x;
+    int item = xcd_remap(blockIdx.x, Gd);
+    if (item >= nitems) return;
+    typename T::vec8 qf[G::NKS], qn[G::NKS];
+    prefetch_kv(item);
+    load_q(qf, item);
+    commit_kv();
     __syncthreads();
 
-    // T[c][i]: i<32 -> q.rel_h[i], i>=32 -> q.rel_w[i-32], pre-divided by the softmax scale
-    float U[WS], V[WS];
-    {
-        f32x16 acc[2];
+    while (true) {
+        const int next = item + Gd;
+        const bool has_next = next < nitems;
+        if (has_next) {                                   // in flight during this item's compute
+            prefetch_kv(next);
+            load_q(qn, next);
+        }
+        // T[c][i]: i<32 -> q.rel_h[i], i>=32 -> q.rel_w[i-32], pre-divided by the softmax scale
+        float U[WS], V[WS];
+        {
+            f32x16 acc[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        qk_tile<T, HD, 2>(acc, qf, sTab, lane);
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            qk_tile<T, HD, 2>(acc, qf, sTab, lane);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int il = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    sT[c * 65 + il] = acc[t][r] * inv_scale;
+                }
+            // table rows 27..31 are zero, so out-of-window slots (qh, qw up to 15) read zeros
+#pragma unroll
+            for (int k = 0; k < WS; ++k) {
+                U[k] = sT[c * 65 + (qh - k + WS - 1)];
+                V[k] = sT[c * 65 + 32 + (qw - k + WS - 1)];
+            }
+        }
+        SoftmaxState<G::NDT> st;
+        st.init();
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            f32x16 s[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int il = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                sT[c * 65 + il] = acc[t][r] * inv_scale;
+                // key index of this element for lane half 0 / 1: compile-time after unrolling
+                const int k0 = 32 * j + (r & 3) + 8 * (r >> 2), k1 = k0 + 4;
+                const float b0 = k0 < NTOK ? U[(k0 < NTOK ? k0 : 0) / WS] + V[(k0 < NTOK ? k0 : 0) % WS] : 0.f;
+                const float b1 = k1 < NTOK ? U[(k1 < NTOK ? k1 : 0) / WS] + V[(k1 < NTOK ? k1 : 0) % WS] : 0.f;
+                s[0][r] = h ? b1 : b0;
             }
-        // table rows 27..31 are zero, so out-of-window slots (qh, qw up to 15) read zeros
-#pragma unroll
-        for (int k = 0; k < WS; ++k) {
-            U[k] = sT[c * 65 + (qh - k + WS - 1)];
-            V[k] = sT[c * 65 + 32 + (qw - k + WS - 1)];
+            qk_tile<T, HD, 1>(s, qf, sK + j * 32 * G::KS, lane);
+            softmax_pv<T, HD, 1>(st, s, c1, NTOK - 32 * j, sV + j * 32 * G::VS, lane);
         }
-    }
-
-    SoftmaxState<G::NDT> st;
-    st.init();
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        f32x16 s[1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // key index of this element for lane half 0 / 1: compile-time after unrolling
-            const int k0 = 32 * j + (r & 3) + 8 * (r >> 2), k1 = k0 + 4;
-            const float b0 = k0 < NTOK ? U[(k0 < NTOK ? k0 : 0) / WS] + V[(k0 < NTOK ? k0 : 0) % WS] : 0.f;
-            const float b1 = k1 < NTOK ? U[(k1 < NTOK ? k1 : 0) / WS] + V[(k1 < NTOK ? k1 : 0) % WS] : 0.f;
-            s[0][r] = h ? b1 : b0;
+        {
+            int b, win, head;
+            decode(item, b, win, head);
+            const QInfo qo = q_info(item);
+            u16* orow = p.out + qo.row * p.out_stride + head * HD;
+            store_out<T, HD>(st, orow, lane, qo.valid);
         }
-        qk_tile<T, HD, 1>(s, qf, sK + j * 32 * G::KS, lane);
-        softmax_pv<T, HD, 1>(st, s, c1, NTOK - 32 * j, sV + j * 32 * G::VS, lane);
+        if (!has_next) break;
+        __syncthreads();                                  // every wave is done with this item's K / V
+        commit_kv();
+#pragma unroll
+        for (int ks = 0; ks < G::NKS; ++ks) qf[ks] = qn[ks];
+        item = next;
+        __syncthreads();
     }
-    u16* orow = p.out + ((size_t)b * GRID * GRID + tok) * p.out_stride + head * HD;
-    store_out<T, HD>(st, orow, lane, qvalid);
 }
 
 }  // namespace wm

@@ -357,8 +357,18 @@ int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
         attr_set = true;
     }
     // useful work only: 4096 real queries x 196 keys
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int nitems = 25 * a.heads * batch;
+    const int grid = nitems < num_cu ? nitems : num_cu;
     Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);
-    hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(25 * a.heads * batch), dim3(448), L::TOTAL, s, a);
+    hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(grid), dim3(448), L::TOTAL, s, a, nitems);
     HIP_TRY(hipGetLastError());
     return 0;
 }
