@@ -49,17 +49,38 @@ def build_model(model_type: str, precision: str, device: torch.device):
     return model, sd
 
 
-def cpu_baseline(model_type: str, sd) -> dict:
-    """Oracle (CPU port of the reference, fp32) on one tile; checker code used here only as a timed baseline."""
+def cpu_baseline(model_type: str, sd, model, device) -> tuple:
+    """Oracle (CPU port of the reference, fp32) on one tile, timed; and the BASELINE metric's second half,
+    "mAP vs CPU ref": the GPU path's detections on the same tile scored against the CPU detections as ground truth
+    (own COCO-style evaluator, wildlifemapper_amd/coco_eval.py).  Checker code, used here only as a baseline."""
     from oracle import wm_oracle as O
+    from wildlifemapper_amd.coco_eval import map_vs_reference
+    from wildlifemapper_amd.engine import split_records
     x = torch.from_numpy(synth.make_batch(0, 1))
     cfg = O.OracleCfg.from_model_type(model_type)
     threads = torch.get_num_threads()
     t0 = time.time()
-    O.model_forward(x, sd, cfg)
+    ref = O.model_forward(x, sd, cfg)
     dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "tiles/s", "cores": threads, "kind": "port",
+    base = {"value": 1.0 / dt, "unit": "tiles/s", "cores": threads, "kind": "port",
             "sample": f"1 {model_type} tile, full path fp32 (fft+encoder+decoder), {dt:.1f} s, torch CPU {threads} threads"}
+    ts = torch.tensor([[1024, 1024]])
+    det_ref = O.detect(O.postprocess(ref["pred_logits"], ref["pred_boxes"], ts)[0])
+    with torch.no_grad():
+        out = model.detect(x.to(device), ts.float().to(device))
+    rec = split_records(out["records"].cpu())
+    kept = (rec["flags"][0] & 4) != 0
+    order = torch.argsort(rec["nms_rank"][0][kept])
+    pred = {0: {"boxes": rec["boxes"][0][kept][order].numpy(), "scores": rec["scores"][0][kept][order].numpy(),
+                "labels": rec["labels"][0][kept][order].numpy()}}
+    gt = {0: {"boxes": det_ref["boxes"].numpy(), "scores": det_ref["scores"].numpy(), "labels": det_ref["labels"].numpy()}}
+    m = map_vs_reference(pred, gt)
+    lg = out["pred_logits"].cpu()
+    parity = {"mAP": round(m["mAP"], 4), "mAP50": round(m["mAP50"], 4), "tiles": 1,
+              "detections_gpu": int(kept.sum()), "detections_cpu": int(len(det_ref["scores"])),
+              "logits_rel_l2": float(((lg - ref["pred_logits"]).norm() / ref["pred_logits"].norm()).item()),
+              "evaluator": "own COCO-style bbox AP@[.5:.95], CPU-reference detections as ground truth"}
+    return base, parity
 
 
 def main() -> None:
@@ -185,9 +206,9 @@ def main() -> None:
             "roofline": roofline, "kernel_classes": classes,
         }
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(a.model, sd)
+            line["cpu_baseline"], line["map_vs_cpu_ref"] = cpu_baseline(a.model, sd, model, device)
         else:
-            line["cpu_baseline"] = None
+            line["cpu_baseline"], line["map_vs_cpu_ref"] = None, None
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -93,6 +93,11 @@ int wm_finalize_weights(wm_handle* h);
 
 /* ---- the path ------------------------------------------------------------- */
 
+/* Input pipeline in front of the path: uint8 HWC images [B,h,w,3] (h, w <= 1024) -> the model's
+ * input tensor [B,3,1024,1024] fp32: ToTensor + Normalize(ImageNet) of dataloader_coco.py:286-292 and the zero
+ * padding to 1024 x 1024 of segment_anything/utils/misc.py:46-67 (the resize to 768 is not part of it). */
+int wm_preprocess_u8(const uint8_t* img_dev, float* out_dev, int batch, int height, int width, void* stream);
+
 /* MedSAM.fft, segment_anything/network.py:36-57.
  * x (B,3,1024,1024) fp32 -> hfc (B,1,1024,1024) fp32. */
 int wm_hfc_fft(wm_handle* h, const float* x_dev, float* hfc_dev, int batch, void* stream);

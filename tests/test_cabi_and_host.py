@@ -102,3 +102,25 @@ def test_nested_tensor_collation():
     assert bool(nt.mask[0, 0, 512]) and not bool(nt.mask[0, 767, 511]) and not bool(nt.mask[1].any())
     imgs, tg = custom_collate([{"image": a, "target": {"id": 1}}, {"image": b, "target": {"id": 2}}])
     assert imgs.tensors.shape[0] == 2 and tg[1]["id"] == 2
+
+
+def test_build_sam_checkpoint_filter(tmp_path):
+    """_build_sam (build_sam.py:311-322): a SAM checkpoint is loaded with mask_decoder.* keys that are not
+    part of the transformer dropped, strict=False; both a bare state dict and {'model': sd} are accepted."""
+    from wildlifemapper_amd.segment_anything import build_sam_vit_b
+    sam0, _, _ = build_sam_vit_b(None, None)
+    sd = {k: v.clone() for k, v in sam0.state_dict().items()}
+    for k in sd:
+        sd[k] = torch.full_like(sd[k], 0.25)
+    sd["mask_decoder.output_upscaling.0.weight"] = torch.zeros(3)          # vanilla-SAM key that does not exist here
+    path = tmp_path / "sam.pth"
+    torch.save(sd, path)
+    sam1, _, _ = build_sam_vit_b(str(path), None)
+    got = sam1.state_dict()
+    assert float(got["image_encoder.blocks.0.attn.qkv.weight"].mean()) == 0.25
+    assert float(got["mask_decoder.transformer.layers.0.norm1.weight"].mean()) == 0.25
+    # non-transformer decoder weights keep their fresh initialisation
+    assert float(got["mask_decoder.mask_tokens.weight"].abs().mean()) != 0.25
+    torch.save({"model": sd, "epoch": 3}, path)
+    sam2, _, _ = build_sam_vit_b(str(path), None)
+    assert float(sam2.state_dict()["image_encoder.pos_embed"].mean()) == 0.25

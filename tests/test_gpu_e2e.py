@@ -216,6 +216,43 @@ def test_dropin_modules_and_batch_invariance():
     assert set(res[0]) == {"scores", "labels", "boxes"}
 
 
+def test_evaluate_harness(golden_dir):
+    """inference.evaluate (inference.py:30-89): loader of (NestedTensor, targets) -> per-image detections,
+    checked against PostProcess of the golden logits."""
+    from types import SimpleNamespace
+    from wildlifemapper_amd.inference import evaluate
+    from wildlifemapper_amd.segment_anything.build_sam import InferenceCriterion
+    fx = np.load(os.path.join(golden_dir, "e2e_vit_b.npz"))
+    m, post = _model("vit_b", "fp16")
+    x = torch.from_numpy(synth.make_batch(0, 2))
+    loader = []
+    for i in range(2):
+        tgt = [{"image_id": torch.tensor([100 + i]), "orig_size": torch.tensor([1024, 1024])}]
+        loader.append((nested_tensor_from_tensor_list([x[i]]), tgt))
+    stats, dets = evaluate(m, InferenceCriterion(), {"bbox": post}, loader, None, G.dev(), SimpleNamespace(batch_size=1))
+    assert stats["images"] == 2 and set(dets) == {100, 101}
+    ref = O.postprocess(torch.from_numpy(fx["pred_logits"]), torch.from_numpy(fx["pred_boxes"]), torch.tensor([[1024, 1024]] * 2))
+    for i in range(2):
+        d = dets[100 + i]
+        assert len(d["scores"]) == len(ref[i]["scores"])
+        np.testing.assert_allclose(d["scores"].numpy(), ref[i]["scores"].numpy(), atol=2e-4)
+        np.testing.assert_array_equal(d["labels"].numpy(), ref[i]["labels"].numpy())
+        np.testing.assert_allclose(d["boxes"].numpy(), ref[i]["boxes"].numpy(), atol=0.2)
+
+
+def test_input_pipeline_bit_exact():
+    """uint8 HWC -> normalised, zero-padded fp32 tile: bit-exact with the numpy pipeline (synth.normalize_tile)."""
+    from wildlifemapper_amd.preprocess import tiles_from_u8
+    full = np.stack([synth.make_tile_u8(t) for t in (0, 1)])
+    got = tiles_from_u8(torch.from_numpy(full).to(G.dev())).cpu().numpy()
+    want = np.stack([synth.normalize_tile(u) for u in full])
+    assert np.array_equal(got, want)
+    small = full[:, :768, :700]                                   # short image: top-left aligned, zero padded
+    got = tiles_from_u8(torch.from_numpy(np.ascontiguousarray(small)).to(G.dev())).cpu().numpy()
+    assert np.array_equal(got[:, :, :768, :700], want[:, :, :768, :700])
+    assert not got[:, :, 768:, :].any() and not got[:, :, :, 700:].any()
+
+
 def test_cpu_tensor_fails_loudly():
     m, _ = _model("vit_b", "fp16")
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -42,6 +42,7 @@ SYMBOLS = {
     "wm_destroy": (_I, [_P]),
     "wm_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_L), _I]),
     "wm_finalize_weights": (_I, [_P]),
+    "wm_preprocess_u8": (_I, [_P, _P, _I, _I, _I, _P]),
     "wm_hfc_fft": (_I, [_P, _P, _P, _I, _P]),
     "wm_encoder_forward": (_I, [_P, _P, _P, _P, _I, _P]),
     "wm_decoder_forward": (_I, [_P, _P, _P, _P, _I, _P]),

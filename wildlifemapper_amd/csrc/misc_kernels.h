@@ -149,4 +149,36 @@ __global__ __launch_bounds__(256) void cvt_16_to_f32_kernel(const u16* __restric
     }
 }
 
+// ---------------------------------------------------------------------------
+// Input pipeline: uint8 HWC image (h, w <= 1024) -> fp32 CHW tile on the zero 1024 x 1024
+// canvas, top-left aligned: ToTensor (/255), Normalize(ImageNet mean/std) (dataloader_coco.py:286-292,
+// augmentation.py:229-249) and the fixed-1024 zero padding of nested_tensor_from_tensor_list
+// (utils/misc.py:46-67) in one pass.  in [B,h,w,3] u8, out [B,3,1024,1024] fp32.  One thread per 4 pixels.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ in, float* __restrict__ out,
+                                                            int B, int h, int w) {
+#pragma clang fp contract(off)
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    const int64_t total = (int64_t)B * 1024 * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x4 = (int)(i & 255) * 4;
+        const int y = (int)((i >> 8) & 1023);
+        const int64_t b = i >> 18;
+        f32x4 v[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (y < h) {
+            const unsigned char* row = in + ((b * h + y) * (int64_t)w) * 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = x4 + j;
+                if (x < w) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c][j] = ((float)row[x * 3 + c] / 255.0f - mean[c]) / stdv[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *(f32x4*)(out + ((b * 3 + c) * 1024 + y) * (int64_t)1024 + x4) = v[c];
+    }
+}
+
 }  // namespace wm

@@ -1047,6 +1047,16 @@ extern "C" int wm_op_cvt_16_to_f32(const void* in_dev, float* out_dev, int64_t n
     return 0;
 }
 
+extern "C" int wm_preprocess_u8(const uint8_t* img_dev, float* out_dev, int batch, int height, int width, void* stream) {
+    if (!img_dev || !out_dev) return fail("wm_preprocess_u8: null buffer");
+    if (batch <= 0 || height <= 0 || width <= 0 || height > 1024 || width > 1024)
+        return fail("wm_preprocess_u8: batch %d, %dx%d outside 1..1024 (larger images are cropped by the caller, utils/misc.py:57-60)", batch, height, width);
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for((int64_t)batch * 1024 * 256)), dim3(256), 0, (hipStream_t)stream,
+                       img_dev, out_dev, batch, height, width);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev, int res_mod,
                             float* out_f32_dev, void* out_16_dev, int M, int N, int K, int act, int precision, void* stream) {
     return launch_gemm16(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, bias_dev, residual_dev, res_mod, out_f32_dev, out_16_dev, M, N, K, act);
