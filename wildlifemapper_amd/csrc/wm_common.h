@@ -64,22 +64,30 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // exact-erf GELU of common.py:26 (nn.GELU default).  Two forms:
 //   gelu_erf      - libm erff, used where the result stays fp32 (gemm32);
-//   gelu_erf_fast - Abramowitz-Stegun 7.1.26 erf (|abs err| <= 1.5e-7), ~15 VALU instead of ~50; used in the
-//                   16-bit GEMM epilogue, whose output is rounded to 2^-9 / 2^-12 relative anyway.
+//   gelu_erf_fast - erf as a clamped rational x*P(x^2)/Q(x^2) (degree 6/4 in x^2, the form used by Eigen/XLA's float
+//                   erf; max abs error 4.2e-7 against math.erf over [-6,6], checked on the host): 13 FMAs + one
+//                   v_rcp_f32, all but the rcp packable, against two transcendentals and a branchy tail for erff.
+//                   Used in the 16-bit GEMM epilogue, whose output is rounded to 2^-9 / 2^-12 relative anyway.
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    float poly = 1.061405429f;
-    poly = poly * t - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = 1.0f - poly * t * e;
-    const float erf = x < 0.f ? -erf_abs : erf_abs;
+    float z = x * 0.70710678118654752440f;
+    z = fminf(fmaxf(z, -4.0f), 4.0f);
+    const float z2 = z * z;
+    float p = -2.72614225801306e-10f;
+    p = p * z2 + 2.77068142495902e-08f;
+    p = p * z2 - 2.10102402082508e-06f;
+    p = p * z2 - 5.69250639462346e-05f;
+    p = p * z2 - 7.34990630326855e-04f;
+    p = p * z2 - 2.95459980854025e-03f;
+    p = p * z2 - 1.60960333262415e-02f;
+    float q = -1.45660718464996e-05f;
+    q = q * z2 - 2.13374055278905e-04f;
+    q = q * z2 - 1.68282697438203e-03f;
+    q = q * z2 - 7.37332916720468e-03f;
+    q = q * z2 - 1.42647390514189e-02f;
+    const float erf = (p * z) * __builtin_amdgcn_rcpf(q);
     return 0.5f * x * (1.0f + erf);
 }
 
