@@ -78,12 +78,19 @@ template <int NDT> struct SoftmaxState {
     }
 };
 
-// One key tile of NT*32 keys.  s[t] hold the raw accumulators (bias/scale already
-// folded so that log2-domain score = c1 * s).  kvalid: number of valid keys in the
-// tile (keys >= kvalid are masked).  sV: LDS address of the tile's V rows.
+// One key tile of NT*32 keys.  s[t] hold the raw accumulators; the log2-domain score of an element is
+// c1 * (s + tile_bias) (c1 = softmax scale * log2 e; tile_bias = a per-query constant of this tile, e.g. the
+// rel-pos kh-term divided by the scale).  kvalid: number of valid keys in the tile (keys >= kvalid are masked).
+// sV: LDS address of the tile's V rows.
+// VALU budget per score (this loop is VALU-bound next to 22 MFMAs per tile): max, one FMA folding scale, bias and
+// running max into the exp2 argument, exp2, sum, convert.  The O accumulators are rescaled only when the running
+// max grew by more than RESCALE_THR (log2 units), so most tiles skip the O-wide multiply; until then P values are
+// bounded by 2^RESCALE_THR instead of 1, harmless in fp32 accumulators and for 16-bit floating P.
+constexpr float RESCALE_THR = 6.0f;
+
 template <class T, int HD, int NT>
 __device__ __forceinline__ void softmax_pv(SoftmaxState<AttnGeom<HD>::NDT>& st, f32x16 (&s)[NT],
-                                           float c1, int kvalid, const char* sV, int lane) {
+                                           float c1, float tile_bias, int kvalid, const char* sV, int lane) {
     using G = AttnGeom<HD>;
     const int h = lane >> 5;
     float mx = -1e30f;
@@ -92,29 +99,35 @@ __device__ __forceinline__ void softmax_pv(SoftmaxState<AttnGeom<HD>::NDT>& st, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-            float v = s[t][r] * c1;
-            if (key >= kvalid) v = -1e30f;
-            s[t][r] = v;
-            mx = fmaxf(mx, v);
+            if (key >= kvalid) s[t][r] = -1e30f;          // folds away when the tile is full
+            mx = fmaxf(mx, s[t][r]);
         }
+    mx = (mx + tile_bias) * c1;
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(st.m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(st.m - m_new);
-    st.m = m_new;
+    // defer-max: keep the old reference point unless some query's max grew by more than the threshold
+    float m_use = st.m;
+    if (!__all(mx - st.m <= RESCALE_THR)) {
+        const float m_new = fmaxf(st.m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(st.m - m_new);
+        st.l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < G::NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
+        st.m = m_new;
+        m_use = m_new;
+    }
+    const float off = tile_bias * c1 - m_use;
     float ls = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(s[t][r] - m_new);
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][r], c1, off));
             s[t][r] = pv;
             ls += pv;
         }
-    st.l = st.l * alpha + ls;
-#pragma unroll
-    for (int dt = 0; dt < G::NDT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
+    st.l += ls;
 
     // P^T fragments -> O^T += V^T P^T.  k-step ks covers keys 16*ks .. 16*ks+15 of the tile.
     const int g = lane >> 4;
@@ -336,12 +349,11 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
         const char* sK = sKV + buf * (L::K_BYTES + L::V_BYTES);
         const char* sV = sK + L::K_BYTES;
         f32x16 s[2];
+        float rh = 0.f;
         if constexpr (REL) {
-            const float rh = sRelH[j * 32 + c];
+            rh = sRelH[j * 32 + c];                       // kh-term: one scalar per query and tile, applied inside the exp2 FMA
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[t][r] = relw[t][r] + rh;
+            for (int t = 0; t < 2; ++t) s[t] = relw[t];    // kw-term: the accumulators' initial value
         } else {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
                 for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
         }
         qk_tile<T, HD, 2>(s, qf, sK, lane);
-        softmax_pv<T, HD, 2>(st, s, c1, 64, sV, lane);
+        softmax_pv<T, HD, 2>(st, s, c1, rh, 64, sV, lane);
         if (j + 1 < ntiles) commit(buf ^ 1);
         __syncthreads();
     }
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
                 s[0][r] = h ? b1 : b0;
             }
             qk_tile<T, HD, 1>(s, qf, sK + j * 32 * G::KS, lane);
-            softmax_pv<T, HD, 1>(st, s, c1, NTOK - 32 * j, sV + j * 32 * G::VS, lane);
+            softmax_pv<T, HD, 1>(st, s, c1, 0.f, NTOK - 32 * j, sV + j * 32 * G::VS, lane);
         }
         {
             int b, win, head;
