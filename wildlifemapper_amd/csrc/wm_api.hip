@@ -18,6 +18,7 @@
 #include "gemm16.h"
 #include "gemm16_v2.h"
 #include "gemm16_v3.h"
+#include "gemm16_v5.h"
 #include "gemm32.h"
 #include "misc_kernels.h"
 #include "wm_common.h"
@@ -230,10 +231,27 @@ int launch_gemm16v3_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     return 0;
 }
 
+template <class T16, int BN>
+int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
+    using G = G3<BN, 4>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v5_kernel<T16, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        attr_set = true;
+    }
+    const int grid = (a.M / 256) * (a.N / BN);
+    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
+               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
+    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN>), dim3(grid), dim3(512), G::LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // fraction of the last round of workgroup slots that is filled
 static double round_eff(long tiles, long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); }
 
-// WM_GEMM_MODE (A/B runs): 0 = auto: 256x320 / 256x256 8-wave tiles (gemm16_v3.h), else 256x160/128 (gemm16_v2.h)
+// WM_GEMM_MODE (A/B runs): 0 = auto: 256x320 / 256x256 8-wave tiles with staggered wave groups (gemm16_v5.h), else 256x160/128
+//                          4 = as 0 but lockstep waves (gemm16_v3.h)
 //                          1 = 128x128 kernel only   2 = gemm16_v2.h only   3 = 4-wave 256x160/128 (two workgroups per CU)
 static int gemm_mode() {
     static const int m = getenv("WM_GEMM_MODE") ? atoi(getenv("WM_GEMM_MODE")) : 0;
@@ -250,7 +268,11 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
     Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act, 0, nullptr};
     const int mode = gemm_mode();
     if (M % 256 == 0 && mode != 1) {
-        if (mode == 0) {
+        if (mode == 0 && K / 32 >= 2) {      // staggered wave groups (gemm16_v5.h)
+            if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320>(h, s, a)), (launch_gemm16v5_t<FP16, 320>(h, s, a)));
+            if (N % 256 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 256>(h, s, a)), (launch_gemm16v5_t<FP16, 256>(h, s, a)));
+        }
+        if (mode == 0 || mode == 4) {
             if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v3_t<BF16, 320, 4>(h, s, a)), (launch_gemm16v3_t<FP16, 320, 4>(h, s, a)));
             if (N % 256 == 0) return WM_BY_PREC((launch_gemm16v3_t<BF16, 256, 4>(h, s, a)), (launch_gemm16v3_t<FP16, 256, 4>(h, s, a)));
         }
