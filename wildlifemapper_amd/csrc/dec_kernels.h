@@ -6,60 +6,92 @@
 namespace wm {
 
 // ---------------------------------------------------------------------------
-// softmax(q k^T / sqrt(hd)) v in fp32 (transformer.py:225-238).  One wave per
-// (tile, head, query); lanes stride over keys with a per-lane online softmax,
-// merged across the wave at the end.  q [B,Nq,heads*HD], k/v [B,Nk,heads*HD].
-// grid (Nq, heads, B), 64 threads.
+// softmax(q k^T / sqrt(hd)) v in fp32 (transformer.py:225-238).  One wave per (tile, head, QB queries): lanes
+// stride over the keys with a per-lane online softmax per query, merged across the wave at the end.  QB queries
+// share every K / V row a lane loads (the token->image attention reads 4096 keys for only 51 queries, so the
+// K / V traffic, not the arithmetic, is what costs).  q [B,Nq,heads*HD], k/v [B,Nk,heads*HD].
+// With NW > 1 the keys are additionally split over NW waves of the workgroup and merged through LDS.
+// grid (ceil(Nq / QB), heads, B), 64 * NW threads.
 // ---------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(64) void mha32_kernel(const float* __restrict__ q, const float* __restrict__ k,
+template <int HD, int QB, int NW = 1>
+__global__ __launch_bounds__(64 * NW) void mha32_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                    const float* __restrict__ v, float* __restrict__ out,
                                                    int nq, int nk, int heads) {
-    const int lane = threadIdx.x;
-    const int qi = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q0 = blockIdx.x * QB, head = blockIdx.y, b = blockIdx.z;
     const int C = heads * HD;
     const float scale = 1.0f / sqrtf((float)HD);
-    const float* qp = q + ((size_t)b * nq + qi) * C + head * HD;
-    float qv[HD];
+    float qv[QB][HD], m[QB], l[QB], acc[QB][HD];
 #pragma unroll
-    for (int d = 0; d < HD; d += 4) {
-        const f32x4 t = *(const f32x4*)(qp + d);
-        qv[d] = t[0]; qv[d + 1] = t[1]; qv[d + 2] = t[2]; qv[d + 3] = t[3];
+    for (int i = 0; i < QB; ++i) {
+        const int qi = min(q0 + i, nq - 1);                       // tail queries recompute the last one; not stored
+        const float* qp = q + ((size_t)b * nq + qi) * C + head * HD;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const f32x4 t = *(const f32x4*)(qp + d);
+            qv[i][d] = t[0]; qv[i][d + 1] = t[1]; qv[i][d + 2] = t[2]; qv[i][d + 3] = t[3];
+        }
+        m[i] = -1e30f; l[i] = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[i][d] = 0.f;
     }
-    float m = -1e30f, l = 0.f, acc[HD];
-#pragma unroll
-    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
-    for (int key = lane; key < nk; key += 64) {
+    for (int key = wave * 64 + lane; key < nk; key += 64 * NW) {
         const float* kp = k + ((size_t)b * nk + key) * C + head * HD;
         const float* vp = v + ((size_t)b * nk + key) * C + head * HD;
-        float s = 0.f;
+        float kr[HD], vr[HD];
 #pragma unroll
         for (int d = 0; d < HD; d += 4) {
             const f32x4 t = *(const f32x4*)(kp + d);
-            s += qv[d] * t[0] + qv[d + 1] * t[1] + qv[d + 2] * t[2] + qv[d + 3] * t[3];
+            const f32x4 u = *(const f32x4*)(vp + d);
+            kr[d] = t[0]; kr[d + 1] = t[1]; kr[d + 2] = t[2]; kr[d + 3] = t[3];
+            vr[d] = u[0]; vr[d + 1] = u[1]; vr[d + 2] = u[2]; vr[d + 3] = u[3];
         }
-        s *= scale;
-        const float mn = fmaxf(m, s);
-        const float a = expf(m - mn), pe = expf(s - mn);
-        l = l * a + pe;
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) {
-            const f32x4 t = *(const f32x4*)(vp + d);
-            acc[d] = acc[d] * a + pe * t[0];
-            acc[d + 1] = acc[d + 1] * a + pe * t[1];
-            acc[d + 2] = acc[d + 2] * a + pe * t[2];
-            acc[d + 3] = acc[d + 3] * a + pe * t[3];
+        for (int i = 0; i < QB; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4)
+                s += qv[i][d] * kr[d] + qv[i][d + 1] * kr[d + 1] + qv[i][d + 2] * kr[d + 2] + qv[i][d + 3] * kr[d + 3];
+            s *= scale;
+            const float mn = fmaxf(m[i], s);
+            const float a = expf(m[i] - mn), pe = expf(s - mn);
+            l[i] = l[i] * a + pe;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[i][d] = acc[i][d] * a + pe * vr[d];
+            m[i] = mn;
         }
-        m = mn;
     }
-    const float M = wave_max(m);
-    const float f = expf(m - M);          // lanes that saw no key: m = -1e30 -> f = 0
-    const float L = wave_sum(l * f);
-    float* op = out + ((size_t)b * nq + qi) * C + head * HD;
+    __shared__ float part[NW][QB][HD + 2];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) {
-        const float o = wave_sum(acc[d] * f);
-        if (lane == 0) op[d] = o / L;
+    for (int i = 0; i < QB; ++i) {
+        const float M = wave_max(m[i]);
+        const float f = expf(m[i] - M);          // lanes that saw no key: m = -1e30 -> f = 0
+        const float L = wave_sum(l[i] * f);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            const float o = wave_sum(acc[i][d] * f);
+            if (lane == 0) part[wave][i][d] = o;
+        }
+        if (lane == 0) { part[wave][i][HD] = M; part[wave][i][HD + 1] = L; }
+    }
+    __syncthreads();
+    // merge the NW partial softmaxes: thread (i, d) of the first QB*HD threads
+    const int t = threadIdx.x;
+    if (t < QB * HD) {
+        const int i = t / HD, d = t % HD;
+        if (q0 + i < nq) {
+            float M = part[0][i][HD];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) M = fmaxf(M, part[w][i][HD]);
+            float L = 0.f, o = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float f = expf(part[w][i][HD] - M);
+                L += part[w][i][HD + 1] * f;
+                o += part[w][i][d] * f;
+            }
+            out[((size_t)b * nq + q0 + i) * C + head * HD + d] = o / L;
+        }
     }
 }
 

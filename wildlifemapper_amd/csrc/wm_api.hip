@@ -429,8 +429,12 @@ int launch_mha16(wm_handle* h, hipStream_t s, int prec, const void* q, int qs, c
 int launch_mha32(wm_handle* h, hipStream_t s, const float* q, const float* k, const float* v, float* out, int batch,
                  int heads, int hd, int nq, int nk) {
     Bracket br(h, s, WM_KCLASS_OTHER, 4.0 * batch * heads * (double)nq * nk * hd, 0.0);
-    if (hd == 16) hipLaunchKernelGGL(mha32_kernel<16>, dim3(nq, heads, batch), dim3(64), 0, s, q, k, v, out, nq, nk, heads);
-    else if (hd == 32) hipLaunchKernelGGL(mha32_kernel<32>, dim3(nq, heads, batch), dim3(64), 0, s, q, k, v, out, nq, nk, heads);
+    // many keys, few queries (token -> image): 4 queries share each K / V row and 4 waves split the keys; otherwise one
+    // query per wave
+    const bool share = nk >= 1024;
+    if (hd == 16 && share) hipLaunchKernelGGL((mha32_kernel<16, 4, 4>), dim3((nq + 3) / 4, heads, batch), dim3(256), 0, s, q, k, v, out, nq, nk, heads);
+    else if (hd == 16) hipLaunchKernelGGL((mha32_kernel<16, 1>), dim3(nq, heads, batch), dim3(64), 0, s, q, k, v, out, nq, nk, heads);
+    else if (hd == 32) hipLaunchKernelGGL((mha32_kernel<32, 1>), dim3(nq, heads, batch), dim3(64), 0, s, q, k, v, out, nq, nk, heads);
     else return fail("mha32: head_dim=%d not built (16, 32)", hd);
     HIP_TRY(hipGetLastError());
     return 0;
