@@ -44,7 +44,7 @@ template <int BN, int WN> struct G3 {
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N <= 8, "extend the table");
+    static_assert(N >= 0 && N <= 10, "extend the table");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -53,7 +53,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
 }
 
 template <class T, int BN, int WN, int AMODE = 0>

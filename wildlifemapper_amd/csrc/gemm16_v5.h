@@ -25,11 +25,21 @@
 
 namespace wm {
 
-template <class T, int BN>
+// DBG (dev only, WM_GEMM_DBG=1): waves 0 and 4 of workgroup 0 record s_memtime at six marks of K-steps 8..17 into
+// p.zero_page (2 x 64 u32).
+template <class T, int BN, int NSLOT = 3, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     using C = G3<BN, 4>;
+    constexpr int AHEAD = NSLOT - 1;                       // K-steps of DMA in flight
+    const bool dbg_nostore = (p.act & 0x100) != 0, dbg_nodma = (p.act & 0x200) != 0, dbg_noissue = (p.act & 0x400) != 0;
     static_assert(C::W_REM == 0 || C::W_REM == 4, "remainder pieces must fall on one wave group");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long wt0 = 0, wt1 = 0, wt2 = 0, we[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (DBG) wt0 = wall_clock64();
+    if (p.conv_c > 0 && blockIdx.x < 256) {               // experiment: de-phase the first round (conv_c = span in 10 ns units)
+        const unsigned long long until = wall_clock64() + (unsigned long long)(((blockIdx.x * 37u) & 15u) * (unsigned)p.conv_c / 16u);
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;               // wave group = wr: rows 0-127 / 128-255
@@ -56,6 +66,8 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     // DMA pieces of this wave for K-step s into ring slot `slot`; EXTRA: waves 0-3 also carry the remainder W piece
     auto stage = [&](int slot, int s, auto extra_tag) {
         constexpr bool EXTRA = decltype(extra_tag)::value;
+        if (dbg_noissue && s >= AHEAD) return;
+        if (dbg_nodma) s = 0;
 #pragma unroll
         for (int i = 0; i < C::A_PIECES; ++i) {
             const int seg = wave * C::A_PIECES + i;
@@ -95,74 +107,187 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
 #pragma unroll
             for (int ni = 0; ni < C::NT; ++ni) acc[mi][ni] = T::mfma16(wf[ni], af[mi], acc[mi][ni]);
     };
-    auto inc = [](int v) { return v == 2 ? 0 : v + 1; };
+    auto inc = [](int v) { return v == NSLOT - 1 ? 0 : v + 1; };
+    auto dec = [](int v) { return v == 0 ? NSLOT - 1 : v - 1; };
     auto wait_step = [&](int s, auto extra_tag) {          // this wave's pieces of step s have landed
         constexpr int P = C::P_LO + (decltype(extra_tag)::value ? 1 : 0);
+        if (dbg_noissue) { wait_vmcnt<0>(); return; }
+        if constexpr (AHEAD == 3) {
+            if (s + 2 < ns) { wait_vmcnt<2 * P>(); return; }
+        }
         if (s + 1 < ns) wait_vmcnt<P>(); else wait_vmcnt<0>();
     };
     auto barrier = [&]() {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    unsigned tmark = 0;
+    auto mark = [&](int s, int k) {
+        if constexpr (DBG) {
+            const unsigned t = (unsigned)__builtin_readcyclecounter();
+            const int idx = (s - 8) * 6 + k;
+            tmark = (lane == idx) ? t : tmark;
+        }
+    };
 
     if (wr == 0) {
         using EX = std::integral_constant<bool, (C::W_REM > 0)>;
-        stage(0, 0, EX{});
-        if (ns > 1) stage(1, 1, EX{});
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i)
+            if (i < ns) stage(i, i, EX{});
         int slot = 0;
 #pragma unroll 1
         for (int s = 0; s < ns; ++s) {
+            mark(s, 0);
             wait_step(s, EX{});
+            mark(s, 1);
             barrier();                                      // X_s
+            if constexpr (DBG) { if (s == 0) wt1 = wall_clock64(); }
+            mark(s, 2);
             read_frags(slot);
-            if (s + 2 < ns) stage(slot == 0 ? 2 : slot - 1, s + 2, EX{});
+            if (s + AHEAD < ns) stage(dec(slot), s + AHEAD, EX{});
+            mark(s, 3);
             barrier();                                      // Y_s
+            mark(s, 4);
             mfmas();
+            mark(s, 5);
             slot = inc(slot);
         }
     } else {
         using EX = std::false_type;
-        stage(0, 0, EX{});
-        if (ns > 1) stage(1, 1, EX{});
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i)
+            if (i < ns) stage(i, i, EX{});
         int slot = 0;
 #pragma unroll 1
         for (int s = 0; s < ns; ++s) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of the slot about to be overwritten are back
+            mark(s, 0);
             wait_step(s, EX{});
+            mark(s, 1);
             barrier();                                      // X_s
+            mark(s, 2);
             if (s > 0) mfmas();                             // step s-1
+            mark(s, 3);
             barrier();                                      // Y_s
+            mark(s, 4);
             read_frags(slot);
-            if (s + 2 < ns) stage(slot == 0 ? 2 : slot - 1, s + 2, EX{});
+            if (s + AHEAD < ns) stage(dec(slot), s + AHEAD, EX{});
+            mark(s, 5);
             slot = inc(slot);
         }
         mfmas();                                            // step ns-1
     }
 
+    if constexpr (DBG) {
+        if (blockIdx.x == 0 && (wave == 0 || wave == 4)) ((unsigned*)p.zero_page)[wr * 64 + lane] = tmark;
+        wt2 = wall_clock64();
+    }
+    // ---- epilogue: bias / activation in registers, then through LDS so that every global access is row-contiguous.
+    // A lane holds C[m = fr][n = 4 fq .. 4 fq + 3] of each 16x16 fragment: stored directly, the 64 lanes of one
+    // instruction hit 64 separate 8-byte pieces (16 rows x 4), which the CU's store path takes one at a time
+    // (measured 13 us per 256x320 tile, a quarter of the kernel).  Staged through the (now idle) ring in passes of
+    // 128 rows (16-bit output) or 64 rows (fp32 output), each thread then moves 16-byte chunks that are consecutive
+    // along the row, and the residual is read the same way.
     const int res_mod = p.res_mod > 0 ? p.res_mod : p.M;
     const int act = p.act & 0xff;
+    f32x4 bias_v[C::NT];
 #pragma unroll
-    for (int mi = 0; mi < C::MT; ++mi) {
-        const int m = m0 + wr * 128 + mi * 16 + fr;
+    for (int ni = 0; ni < C::NT; ++ni)
+        bias_v[ni] = p.bias ? *(const f32x4*)(p.bias + n0 + wc * C::WCOLS + ni * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): this wave's fragment reads are back
+    barrier();                                              // every wave is done with the ring
+    if constexpr (DBG) we[0] = wall_clock64();
+    // one straight-line instance per activation (a per-fragment runtime branch costs more than the stores)
+    auto epilogue = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+    auto finish = [&](f32x4 v, int ni) {
+        v += bias_v[ni];
+        if constexpr (ACT == ACT_GELU) {
+            v = gelu_erf_fast4(v);
+        } else if constexpr (ACT == ACT_RELU) {
 #pragma unroll
-        for (int ni = 0; ni < C::NT; ++ni) {
-            const int n = n0 + wc * C::WCOLS + ni * 16 + fq * 4;
-            f32x4 v = acc[mi][ni];
-            if (p.bias) v += *(const f32x4*)(p.bias + n);
-            if (act == ACT_GELU) {
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        return v;
+    };
+    if (p.out32 == nullptr && p.residual == nullptr) {
+        // 16-bit staging: 2 passes of 4 row-fragments; LDS row = BN * 2 + 16 bytes
+        constexpr int ROWB = BN * 2 + 16, CPR = BN * 2 / 16, MTP = 4, ROWS = 2 * MTP * 16;
+        static_assert(ROWS * ROWB <= NSLOT * C::STAGE && (ROWS * CPR) % 512 == 0, "epilogue staging");
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
-            } else if (act == ACT_RELU) {
+        for (int q = 0; q < C::MT / MTP; ++q) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            for (int mm = 0; mm < MTP; ++mm)
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni) {
+                    const f32x4 v = finish(acc[q * MTP + mm][ni], ni);
+                    typename T::vec4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+                    *(typename T::vec4*)(smem + (wr * MTP * 16 + mm * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 2) = o;
+                }
+            __syncthreads();
+            if constexpr (DBG) we[1 + 2 * q] = wall_clock64();
+#pragma unroll
+            for (int it = 0; it < ROWS * CPR / 512; ++it) {
+                const int c = it * 512 + tid, r = c / CPR, ch = c - r * CPR;
+                const int m = m0 + (r / (MTP * 16)) * 128 + q * MTP * 16 + (r % (MTP * 16));
+                const f32x4 v = *(const f32x4*)(smem + r * ROWB + ch * 16);
+                if (!dbg_nostore) *(f32x4*)((char*)p.out16 + ((size_t)m * p.N + n0) * 2 + ch * 16) = v;
             }
-            if (p.residual) v += *(const f32x4*)(p.residual + (size_t)(m % res_mod) * p.N + n);
-            if (p.out32) *(f32x4*)(p.out32 + (size_t)m * p.N + n) = v;
-            if (p.out16) {
-                typename T::vec4 o;
+            if constexpr (DBG) we[2 + 2 * q] = wall_clock64();
+            if (q + 1 < C::MT / MTP) __syncthreads();
+        }
+    } else {
+        // fp32 staging: 4 passes of 2 row-fragments; LDS row = BN * 4 + 16 bytes
+        constexpr int ROWB = BN * 4 + 16, CPR = BN * 4 / 16, MTP = 2, ROWS = 2 * MTP * 16;
+        static_assert(ROWS * ROWB <= NSLOT * C::STAGE && (ROWS * CPR) % 512 == 0, "epilogue staging");
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
-                *(typename T::vec4*)(p.out16 + (size_t)m * p.N + n) = o;
+        for (int q = 0; q < C::MT / MTP; ++q) {
+#pragma unroll
+            for (int mm = 0; mm < MTP; ++mm)
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni)
+                    *(f32x4*)(smem + (wr * MTP * 16 + mm * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 4) = finish(acc[q * MTP + mm][ni], ni);
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ROWS * CPR / 512; ++it) {
+                const int c = it * 512 + tid, r = c / CPR, ch = c - r * CPR;
+                const int m = m0 + (r / (MTP * 16)) * 128 + q * MTP * 16 + (r % (MTP * 16));
+                f32x4 v = *(const f32x4*)(smem + r * ROWB + ch * 16);
+                if (p.residual) v += *(const f32x4*)(p.residual + (size_t)(m % res_mod) * p.N + n0 + ch * 4);
+                if (dbg_nostore) { if (v[0] == 12345.678f) p.out16[0] = 1; continue; }
+                if (p.out32) *(f32x4*)(p.out32 + (size_t)m * p.N + n0 + ch * 4) = v;
+                if (p.out16) {
+                    typename T::vec4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+                    *(typename T::vec4*)(p.out16 + (size_t)m * p.N + n0 + ch * 4) = o;
+                }
+            }
+            if (q + 1 < C::MT / MTP) __syncthreads();
+        }
+    }
+    };
+    if (act == ACT_GELU) epilogue(std::integral_constant<int, ACT_GELU>{});
+    else if (act == ACT_RELU) epilogue(std::integral_constant<int, ACT_RELU>{});
+    else epilogue(std::integral_constant<int, ACT_NONE>{});
+    if constexpr (DBG) {
+        if (wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // C stores of this wave acknowledged
+            const unsigned long long wt3 = wall_clock64();
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            if (lane == 0) {
+                unsigned long long* r = (unsigned long long*)((char*)p.zero_page + 512) + (size_t)blockIdx.x * 5;
+                r[0] = wt0; r[1] = wt1; r[2] = wt2; r[3] = wt3; r[4] = ((unsigned long long)xcc << 32) | hw;
+                if (blockIdx.x < 8) {
+                    unsigned* e = (unsigned*)p.zero_page + 64 + 40;          // unused tail of the group-1 marks
+                    if (blockIdx.x == 0) for (int i = 0; i < 5; ++i) e[i] = (unsigned)(we[i] - wt2);
+                }
             }
         }
     }

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/wm_hip.h"
@@ -231,18 +232,79 @@ int launch_gemm16v3_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     return 0;
 }
 
-template <class T16, int BN>
+template <class T16, int BN, int NSLOT = 3>
 int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     using G = G3<BN, 4>;
+    constexpr int LDS = NSLOT * G::STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v5_kernel<T16, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v5_kernel<T16, BN, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const int grid = (a.M / 256) * (a.N / BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
-    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN>), dim3(grid), dim3(512), G::LDS, s, a);
+    static const int stagger = getenv("WM_GEMM_STAGGER_US") ? (int)(atof(getenv("WM_GEMM_STAGGER_US")) * 100) : 0;
+    if (stagger > 0 && grid > 256) const_cast<Gemm16Args&>(a).conv_c = stagger;
+    if constexpr (BN == 320 && NSLOT == 3) {
+        static const bool dbg = getenv("WM_GEMM_DBG") != nullptr;          // dev: in-kernel interval timing of workgroup 0
+        static int dbg_left = 3;
+        if (dbg && dbg_left > 0) {
+            --dbg_left;
+            static unsigned* buf = nullptr;
+            const size_t bytes = 512 + (size_t)grid * 40;
+            if (!buf) HIP_TRY(hipMalloc((void**)&buf, 512 + 8192 * 40));
+            if (grid > 8192) return fail("dbg grid");
+            HIP_TRY(hipMemsetAsync(buf, 0, bytes, s));
+            Gemm16Args d = a;
+            d.zero_page = (const u16*)buf;
+            static bool set2 = false;
+            if (!set2) { HIP_TRY(hipFuncSetAttribute((const void*)gemm16v5_kernel<T16, BN, NSLOT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set2 = true; }
+            hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, NSLOT, true>), dim3(grid), dim3(512), LDS, s, d);
+            HIP_TRY(hipStreamSynchronize(s));
+            std::vector<unsigned char> hbuf(bytes);
+            HIP_TRY(hipMemcpy(hbuf.data(), buf, bytes, hipMemcpyDeviceToHost));
+            const unsigned* hb = (const unsigned*)hbuf.data();
+            fprintf(stderr, "[gemm16v5 dbg] M=%d N=%d K=%d  marks relative to group-0 mark 0 of step 8\n", a.M, a.N, a.K);
+            for (int g = 0; g < 2; ++g)
+                for (int st = 0; st < 10; st += 3) {
+                    fprintf(stderr, "  g%d s%2d:", g, st + 8);
+                    for (int k = 0; k < 6; ++k) fprintf(stderr, " %7u", hb[g * 64 + st * 6 + k] - hb[0]);
+                    fprintf(stderr, "\n");
+                }
+            fprintf(stderr, "  workgroup 0 epilogue (10 ns units after loop end): ring free %u, pass0 staged %u, pass0 stores issued %u, pass1 staged %u, pass1 stores issued %u\n",
+                    hb[104], hb[105], hb[106], hb[107], hb[108]);
+            // per-workgroup wall-clock stamps (100 MHz): entry, first barrier passed, loop end, stores acknowledged
+            const unsigned long long* r = (const unsigned long long*)(hbuf.data() + 512);
+            unsigned long long t_min = ~0ull, t_max = 0;
+            for (int i = 0; i < grid; ++i) { t_min = std::min(t_min, r[i * 5]); t_max = std::max(t_max, r[i * 5 + 3]); }
+            double pro = 0, loop = 0, epi = 0;
+            for (int i = 0; i < grid; ++i) {
+                pro += (double)(r[i * 5 + 1] - r[i * 5]); loop += (double)(r[i * 5 + 2] - r[i * 5 + 1]); epi += (double)(r[i * 5 + 3] - r[i * 5 + 2]);
+            }
+            fprintf(stderr, "  span %.2f us; per workgroup avg: prologue %.2f us, loop %.2f us, epilogue %.2f us\n", (t_max - t_min) * 0.01,
+                    pro / grid * 0.01, loop / grid * 0.01, epi / grid * 0.01);
+            // timeline of the workgroups that ran on the CU of workgroup 0 (same XCC + HW_ID CU/SE bits)
+            auto cu_key = [&](int i) { const unsigned long long v = r[i * 5 + 4]; return (v >> 32 << 16) | ((v >> 8) & 0xff) | (((v >> 13) & 7) << 8); };
+            for (int probe : {0, 1}) {
+                fprintf(stderr, "  workgroups sharing the CU of workgroup %d (entry, barrier0, loop end, done; us from first entry):\n", probe);
+                std::vector<int> ids;
+                for (int i = 0; i < grid; ++i) if (cu_key(i) == cu_key(probe)) ids.push_back(i);
+                std::sort(ids.begin(), ids.end(), [&](int x, int y) { return r[x * 5] < r[y * 5]; });
+                for (int i : ids)
+                    fprintf(stderr, "    wg %4d: %7.2f %7.2f %7.2f %7.2f\n", i, (r[i * 5] - t_min) * 0.01, (r[i * 5 + 1] - t_min) * 0.01,
+                            (r[i * 5 + 2] - t_min) * 0.01, (r[i * 5 + 3] - t_min) * 0.01);
+            }
+            // distribution of entry times
+            std::vector<double> ent(grid), fin(grid);
+            for (int i = 0; i < grid; ++i) { ent[i] = (r[i * 5] - t_min) * 0.01; fin[i] = (r[i * 5 + 3] - t_min) * 0.01; }
+            std::sort(ent.begin(), ent.end()); std::sort(fin.begin(), fin.end());
+            fprintf(stderr, "  entry times: min %.2f p25 %.2f p50 %.2f p75 %.2f max %.2f; done: min %.2f p50 %.2f max %.2f\n", ent[0], ent[grid / 4], ent[grid / 2],
+                    ent[3 * grid / 4], ent[grid - 1], fin[0], fin[grid / 2], fin[grid - 1]);
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, NSLOT>), dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -268,7 +330,11 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
     Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act, 0, nullptr};
     const int mode = gemm_mode();
     if (M % 256 == 0 && mode != 1) {
-        if (mode == 0 && K / 32 >= 2) {      // staggered wave groups (gemm16_v5.h)
+        if (mode == 5 && K / 32 >= 3) {      // staggered, 4-slot ring
+            if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320, 4>(h, s, a)), (launch_gemm16v5_t<FP16, 320, 4>(h, s, a)));
+            if (N % 256 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 256, 4>(h, s, a)), (launch_gemm16v5_t<FP16, 256, 4>(h, s, a)));
+        }
+        if ((mode == 0 || mode == 5) && K / 32 >= 2) {      // staggered wave groups (gemm16_v5.h)
             if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320>(h, s, a)), (launch_gemm16v5_t<FP16, 320>(h, s, a)));
             if (N % 256 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 256>(h, s, a)), (launch_gemm16v5_t<FP16, 256>(h, s, a)));
         }

@@ -9,6 +9,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -63,32 +64,53 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // exact-erf GELU of common.py:26 (nn.GELU default).  Two forms:
-//   gelu_erf      - libm erff, used where the result stays fp32 (gemm32);
-//   gelu_erf_fast - erf as a clamped rational x*P(x^2)/Q(x^2) (degree 6/4 in x^2, the form used by Eigen/XLA's float
-//                   erf; max abs error 4.2e-7 against math.erf over [-6,6], checked on the host): 13 FMAs + one
-//                   v_rcp_f32, all but the rcp packable, against two transcendentals and a branchy tail for erff.
-//                   Used in the 16-bit GEMM epilogue, whose output is rounded to 2^-9 / 2^-12 relative anyway.
+//   gelu_erf       - libm erff, used where the result stays fp32 (gemm32);
+//   gelu_erf_fast  - erf(x / sqrt 2) as a clamped rational x P(x^2) / Q(x^2), degree 3/3 in x^2, |x| clamped to
+//                    3.2 sqrt 2 (1 - erf(3.2) = 6e-6).  Least-squares fit weighted for the GELU error (coefficients
+//                    from a host-side fit against scipy.special.erf, evaluated in fp32 in this operation order):
+//                    |GELU error| <= 9.6e-6 for |x| <= 6 and <= 1.7e-6 |x| beyond; erf error <= 3.2e-6.
+//                    Used in the 16-bit GEMM epilogues, whose output is rounded to 2^-9 / 2^-12 relative anyway.
+//   gelu_erf_fast2 - the same on two values with packed fp32 math (v_pk_fma_f32) and ONE v_rcp_f32 for both
+//                    (1 / (Qa Qb) times the other Q): the epilogue of the MLP's first GEMM is VALU-bound on this.
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
+constexpr float GELU_X = 4.525483399593905f;
+constexpr float GELU_P0 = 0.7978911995887756f, GELU_P1 = 0.05407121405005455f, GELU_P2 = 0.007685498800128698f,
+                GELU_P3 = 6.773129280190915e-05f;
+constexpr float GELU_Q1 = 0.2344742864370346f, GELU_Q2 = 0.02365594170987606f, GELU_Q3 = 0.0011780407512560487f;
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-    float z = x * 0.70710678118654752440f;
-    z = fminf(fmaxf(z, -4.0f), 4.0f);
-    const float z2 = z * z;
-    float p = -2.72614225801306e-10f;
-    p = p * z2 + 2.77068142495902e-08f;
-    p = p * z2 - 2.10102402082508e-06f;
-    p = p * z2 - 5.69250639462346e-05f;
-    p = p * z2 - 7.34990630326855e-04f;
-    p = p * z2 - 2.95459980854025e-03f;
-    p = p * z2 - 1.60960333262415e-02f;
-    float q = -1.45660718464996e-05f;
-    q = q * z2 - 2.13374055278905e-04f;
-    q = q * z2 - 1.68282697438203e-03f;
-    q = q * z2 - 7.37332916720468e-03f;
-    q = q * z2 - 1.42647390514189e-02f;
-    const float erf = (p * z) * __builtin_amdgcn_rcpf(q);
-    return 0.5f * x * (1.0f + erf);
+    const float xc = __builtin_amdgcn_fmed3f(x, -GELU_X, GELU_X);
+    const float t = xc * xc;
+    float p = GELU_P3 * t + GELU_P2;
+    p = p * t + GELU_P1;
+    p = p * t + GELU_P0;
+    float q = GELU_Q3 * t + GELU_Q2;
+    q = q * t + GELU_Q1;
+    q = q * t + 1.0f;
+    const float e = (xc * p) * __builtin_amdgcn_rcpf(q);
+    const float hx = 0.5f * x;
+    return hx * e + hx;
+}
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+    const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -GELU_X, GELU_X), __builtin_amdgcn_fmed3f(x[1], -GELU_X, GELU_X)};
+    const f32x2 t = xc * xc;
+    const f32x2 one = {1.0f, 1.0f};
+    f32x2 p = __builtin_elementwise_fma(t, f32x2{GELU_P3, GELU_P3}, f32x2{GELU_P2, GELU_P2});
+    p = __builtin_elementwise_fma(p, t, f32x2{GELU_P1, GELU_P1});
+    p = __builtin_elementwise_fma(p, t, f32x2{GELU_P0, GELU_P0});
+    f32x2 q = __builtin_elementwise_fma(t, f32x2{GELU_Q3, GELU_Q3}, f32x2{GELU_Q2, GELU_Q2});
+    q = __builtin_elementwise_fma(q, t, f32x2{GELU_Q1, GELU_Q1});
+    q = __builtin_elementwise_fma(q, t, one);
+    const float r = __builtin_amdgcn_rcpf(q[0] * q[1]);           // Q in [1, 26]: the product cannot overflow
+    const f32x2 rq = f32x2{q[1], q[0]} * f32x2{r, r};
+    const f32x2 e = (xc * p) * rq;
+    const f32x2 hx = x * f32x2{0.5f, 0.5f};
+    return __builtin_elementwise_fma(hx, e, hx);
+}
+__device__ __forceinline__ f32x4 gelu_erf_fast4(f32x4 v) {
+    const f32x2 a = gelu_erf_fast2(f32x2{v[0], v[1]}), b = gelu_erf_fast2(f32x2{v[2], v[3]});
+    return f32x4{a[0], a[1], b[0], b[1]};
 }
 
 // XCD-aware block remap (bijective for any grid size): blocks that share an XCD
