@@ -14,6 +14,7 @@ ap.add_argument("--prec", default="bf16")
 ap.add_argument("--custom", default="", help="semicolon-separated M,N,K triples")
 ap.add_argument("--act", type=int, default=0)
 ap.add_argument("--f32out", action="store_true")
+ap.add_argument("--residual", action="store_true", help="fp32 residual added in the epilogue (implies --f32out)")
 a = ap.parse_args()
 M = a.batch * 4096
 shapes = {"qkv": (M, 3840, 1280), "proj": (M, 1280, 1280), "lin1": (M, 5120, 1280), "lin2": (M, 1280, 5120),
@@ -30,13 +31,15 @@ for name in names:
     A = G.to16(torch.randn(m, k, device=dev), a.prec)
     W = G.to16(torch.randn(n, k, device=dev) / math.sqrt(k), a.prec)
     bias = torch.randn(n, device=dev)
+    res = torch.randn(m, n, device=dev) if a.residual else None
+    f32 = a.f32out or a.residual
     for _ in range(3):
-        G.gemm16(A, W, bias, act=a.act, prec=a.prec, want32=a.f32out, want16=not a.f32out)
+        G.gemm16(A, W, bias, residual=res, act=a.act, prec=a.prec, want32=f32, want16=not f32)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
-        G.gemm16(A, W, bias, act=a.act, prec=a.prec, want32=a.f32out, want16=not a.f32out)
+        G.gemm16(A, W, bias, residual=res, act=a.act, prec=a.prec, want32=f32, want16=not f32)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.iters

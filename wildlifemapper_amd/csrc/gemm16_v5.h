@@ -130,6 +130,26 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         }
     };
 
+    // fp32 residual (proj / lin2: out = residual + A W^T + b): the residual tile comes in by LDS-DMA, 32 rows (16 per
+    // wave group) per epilogue pass, one pass ahead; pass 0 is requested here and lands beside the ring.
+    constexpr int RP_CPR = BN * 4 / 16, RP_PW = RP_CPR / 16;       // 16-byte chunks per row; DMA pieces per wave and pass
+    constexpr int RES_L0 = NSLOT * C::STAGE, RES_L1 = 45056, RES_BYTES = 32 * BN * 4;
+    static_assert(32 * (BN * 4 + 16) <= RES_L1 && RES_L1 + RES_BYTES <= NSLOT * C::STAGE, "epilogue LDS map");
+    const int res_mod = p.res_mod > 0 ? p.res_mod : p.M;
+    const bool res_wrap = res_mod != p.M;                           // broadcast residual (pos_embed): row m % res_mod
+    auto res_dma = [&](int q) {
+        char* dst = smem + ((q & 1) ? RES_L1 : RES_L0);
+#pragma unroll
+        for (int i = 0; i < RP_PW; ++i) {
+            const int piece = wave * RP_PW + i;
+            const int c = piece * 64 + lane, r = c / RP_CPR, ch = c - r * RP_CPR;
+            int m = m0 + (r >> 4) * 128 + q * 16 + (r & 15);
+            if (res_wrap) m %= res_mod;
+            __builtin_amdgcn_global_load_lds((const char*)(p.residual + (size_t)m * p.N + n0 + ch * 4), WM_LDS_PTR(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    if (p.residual) res_dma(0);
+
     if (wr == 0) {
         using EX = std::integral_constant<bool, (C::W_REM > 0)>;
 #pragma unroll
@@ -189,7 +209,6 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     // (measured 13 us per 256x320 tile, a quarter of the kernel).  Staged through the (now idle) ring in passes of
     // 128 rows (16-bit output) or 64 rows (fp32 output), each thread then moves 16-byte chunks that are consecutive
     // along the row, and the residual is read the same way.
-    const int res_mod = p.res_mod > 0 ? p.res_mod : p.M;
     const int act = p.act & 0xff;
     f32x4 bias_v[C::NT];
 #pragma unroll
@@ -239,6 +258,42 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             if constexpr (DBG) we[2 + 2 * q] = wall_clock64();
             if (q + 1 < C::MT / MTP) __syncthreads();
         }
+    } else if (p.residual != nullptr) {
+        // fp32 + residual: 8 passes of one row-fragment (32 rows).  Pass q: request the residual rows of pass q + 1,
+        // stage this pass's accumulators, wait for this wave's residual pieces of pass q (everything but the DMA
+        // just issued is complete: the C stores of pass q - 1 are older and have had a pass to be acknowledged),
+        // barrier, then add and store 16-byte chunks along the rows.
+        constexpr int ROWB = BN * 4 + 16, NIT = 32 * RP_CPR / 512;
+        static_assert((32 * RP_CPR) % 512 == 0, "epilogue staging");
+#pragma unroll
+        for (int q = 0; q < C::MT; ++q) {
+            if (q + 1 < C::MT) res_dma(q + 1);
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni)
+                *(f32x4*)(smem + (wr * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 4) = finish(acc[q][ni], ni);
+            if (q + 1 < C::MT) wait_vmcnt<RP_PW>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): staging writes done
+            barrier();
+            const char* land = smem + ((q & 1) ? RES_L1 : RES_L0);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = it * 512 + tid, r = c / RP_CPR, ch = c - r * RP_CPR;
+                const int m = m0 + (r >> 4) * 128 + q * 16 + (r & 15);
+                const f32x4 v = *(const f32x4*)(smem + r * ROWB + ch * 16) + *(const f32x4*)(land + c * 16);
+                if (dbg_nostore) { if (v[0] == 12345.678f) p.out16[0] = 1; continue; }
+                if (p.out32) *(f32x4*)(p.out32 + (size_t)m * p.N + n0 + ch * 4) = v;
+                if (p.out16) {
+                    typename T::vec4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+                    *(typename T::vec4*)(p.out16 + (size_t)m * p.N + n0 + ch * 4) = o;
+                }
+            }
+            if (q + 1 < C::MT) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);         // the LDS reads of this pass are back before anyone overwrites
+                barrier();
+            }
+        }
     } else {
         // fp32 staging: 4 passes of 2 row-fragments; LDS row = BN * 4 + 16 bytes
         constexpr int ROWB = BN * 4 + 16, CPR = BN * 4 / 16, MTP = 2, ROWS = 2 * MTP * 16;
@@ -256,7 +311,6 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
                 const int c = it * 512 + tid, r = c / CPR, ch = c - r * CPR;
                 const int m = m0 + (r / (MTP * 16)) * 128 + q * MTP * 16 + (r % (MTP * 16));
                 f32x4 v = *(const f32x4*)(smem + r * ROWB + ch * 16);
-                if (p.residual) v += *(const f32x4*)(p.residual + (size_t)(m % res_mod) * p.N + n0 + ch * 4);
                 if (dbg_nostore) { if (v[0] == 12345.678f) p.out16[0] = 1; continue; }
                 if (p.out32) *(f32x4*)(p.out32 + (size_t)m * p.N + n0 + ch * 4) = v;
                 if (p.out16) {

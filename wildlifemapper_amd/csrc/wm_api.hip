@@ -235,7 +235,8 @@ int launch_gemm16v3_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
 template <class T16, int BN, int NSLOT = 3>
 int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     using G = G3<BN, 4>;
-    constexpr int LDS = NSLOT * G::STAGE;
+    constexpr int LDS = NSLOT * G::STAGE + 32 * BN * 4;        // ring + the first residual landing buffer
+    static_assert(LDS <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm16v5_kernel<T16, BN, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -330,11 +331,7 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
     Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act, 0, nullptr};
     const int mode = gemm_mode();
     if (M % 256 == 0 && mode != 1) {
-        if (mode == 5 && K / 32 >= 3) {      // staggered, 4-slot ring
-            if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320, 4>(h, s, a)), (launch_gemm16v5_t<FP16, 320, 4>(h, s, a)));
-            if (N % 256 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 256, 4>(h, s, a)), (launch_gemm16v5_t<FP16, 256, 4>(h, s, a)));
-        }
-        if ((mode == 0 || mode == 5) && K / 32 >= 2) {      // staggered wave groups (gemm16_v5.h)
+        if (mode == 0 && K / 32 >= 2) {      // staggered wave groups (gemm16_v5.h)
             if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320>(h, s, a)), (launch_gemm16v5_t<FP16, 320>(h, s, a)));
             if (N % 256 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 256>(h, s, a)), (launch_gemm16v5_t<FP16, 256>(h, s, a)));
         }
