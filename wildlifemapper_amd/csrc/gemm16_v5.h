@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     const bool dbg_nostore = (p.act & 0x100) != 0, dbg_nodma = (p.act & 0x200) != 0, dbg_noissue = (p.act & 0x400) != 0;
     static_assert(C::W_REM == 0 || C::W_REM == 4, "remainder pieces must fall on one wave group");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long wt0 = 0, wt1 = 0, wt2 = 0, we[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long wt0 = 0, wt1 = 0, wt2 = 0, mt1 = 0, mt2 = 0, we[6] = {0, 0, 0, 0, 0, 0};
     if constexpr (DBG) wt0 = wall_clock64();
     if (p.conv_c > 0 && blockIdx.x < 256) {               // experiment: de-phase the first round (conv_c = span in 10 ns units)
         const unsigned long long until = wall_clock64() + (unsigned long long)(((blockIdx.x * 37u) & 15u) * (unsigned)p.conv_c / 16u);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             wait_step(s, EX{});
             mark(s, 1);
             barrier();                                      // X_s
-            if constexpr (DBG) { if (s == 0) wt1 = wall_clock64(); }
+            if constexpr (DBG) { if (s == 0) { wt1 = wall_clock64(); mt1 = __builtin_readcyclecounter(); } }
             mark(s, 2);
             read_frags(slot);
             if (s + AHEAD < ns) stage(dec(slot), s + AHEAD, EX{});
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     if constexpr (DBG) {
         if (blockIdx.x == 0 && (wave == 0 || wave == 4)) ((unsigned*)p.zero_page)[wr * 64 + lane] = tmark;
         wt2 = wall_clock64();
+        mt2 = __builtin_readcyclecounter();
     }
     // ---- epilogue: bias / activation in registers, then through LDS so that every global access is row-contiguous.
     // A lane holds C[m = fr][n = 4 fq .. 4 fq + 3] of each 16x16 fragment: stored directly, the 64 lanes of one
@@ -340,7 +341,10 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
                 r[0] = wt0; r[1] = wt1; r[2] = wt2; r[3] = wt3; r[4] = ((unsigned long long)xcc << 32) | hw;
                 if (blockIdx.x < 8) {
                     unsigned* e = (unsigned*)p.zero_page + 64 + 40;          // unused tail of the group-1 marks
-                    if (blockIdx.x == 0) for (int i = 0; i < 5; ++i) e[i] = (unsigned)(we[i] - wt2);
+                    if (blockIdx.x == 0) {
+                        for (int i = 0; i < 5; ++i) e[i] = (unsigned)(we[i] - wt2);
+                        e[5] = (unsigned)(mt2 - mt1); e[6] = (unsigned)(wt2 - wt1);      // loop: s_memtime counts, 10 ns units
+                    }
                 }
             }
         }

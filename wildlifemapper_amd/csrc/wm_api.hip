@@ -275,6 +275,7 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
                 }
             fprintf(stderr, "  workgroup 0 epilogue (10 ns units after loop end): ring free %u, pass0 staged %u, pass0 stores issued %u, pass1 staged %u, pass1 stores issued %u\n",
                     hb[104], hb[105], hb[106], hb[107], hb[108]);
+            fprintf(stderr, "  workgroup 0 main loop: %u s_memtime counts in %.2f us -> %.0f MHz\n", hb[109], hb[110] * 0.01, hb[109] / (hb[110] * 0.01));
             // per-workgroup wall-clock stamps (100 MHz): entry, first barrier passed, loop end, stores acknowledged
             const unsigned long long* r = (const unsigned long long*)(hbuf.data() + 512);
             unsigned long long t_min = ~0ull, t_max = 0;
