@@ -96,6 +96,55 @@ __global__ __launch_bounds__(64 * NW) void mha32_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// The same attention for many queries over a few keys (image -> token, transformer.py:172-178: 4096 queries per
+// tile, NK = 51 keys).  One THREAD per query: K and V rows are uniform across the wave (scalar loads, operands from
+// SGPRs), the NK scores stay in registers (two-pass softmax, no rescaling), nothing crosses lanes.
+// grid (ceil(Nq / 256), heads, B), 256 threads.
+// ---------------------------------------------------------------------------
+template <int HD, int NK>
+__global__ __launch_bounds__(256) void mha32_fewkeys_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, float* __restrict__ out,
+                                                            int nq, int heads) {
+    const int qi = blockIdx.x * 256 + threadIdx.x, head = blockIdx.y, b = blockIdx.z;
+    if (qi >= nq) return;
+    const int C = heads * HD;
+    const float scale = 1.0f / sqrtf((float)HD);
+    float qv[HD];
+    const float* qp = q + ((size_t)b * nq + qi) * C + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+        const f32x4 t = *(const f32x4*)(qp + d);
+        qv[d] = t[0] * scale; qv[d + 1] = t[1] * scale; qv[d + 2] = t[2] * scale; qv[d + 3] = t[3] * scale;
+    }
+    const float* kb = k + (size_t)b * NK * C + head * HD;      // wave-uniform
+    const float* vb = v + (size_t)b * NK * C + head * HD;
+    float sc[NK];
+    float m = -1e30f;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s = fmaf(qv[d], kb[(size_t)j * C + d], s);
+        sc[j] = s;
+        m = fmaxf(m, s);
+    }
+    float l = 0.f, acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        const float pe = expf(sc[j] - m);
+        l += pe;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = fmaf(pe, vb[(size_t)j * C + d], acc[d]);
+    }
+    const float inv = 1.0f / l;
+    float* op = out + ((size_t)b * nq + qi) * C + head * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) *(f32x4*)(op + d) = f32x4{acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv};
+}
+
+// ---------------------------------------------------------------------------
 // PostProcess (build_sam.py:219-258) + score cut and greedy NMS
 // (visualize_prediction.py:150-157; torchvision.ops.nms semantics: stable
 // descending sort, suppress when IoU > thr).  One 64-lane wave per tile, lane =

@@ -496,7 +496,9 @@ int launch_mha32(wm_handle* h, hipStream_t s, const float* q, const float* k, co
     // many keys, few queries (token -> image): 4 queries share each K / V row and 4 waves split the keys; otherwise one
     // query per wave
     const bool share = nk >= 1024;
-    if (hd == 16 && share) hipLaunchKernelGGL((mha32_kernel<16, 4, 4>), dim3((nq + 3) / 4, heads, batch), dim3(256), 0, s, q, k, v, out, nq, nk, heads);
+    if (hd == 16 && nk == NQ && nq >= 1024)       // image -> token: one thread per query, K / V from scalar loads
+        hipLaunchKernelGGL((mha32_fewkeys_kernel<16, NQ>), dim3((nq + 255) / 256, heads, batch), dim3(256), 0, s, q, k, v, out, nq, heads);
+    else if (hd == 16 && share) hipLaunchKernelGGL((mha32_kernel<16, 4, 4>), dim3((nq + 3) / 4, heads, batch), dim3(256), 0, s, q, k, v, out, nq, nk, heads);
     else if (hd == 16) hipLaunchKernelGGL((mha32_kernel<16, 1>), dim3(nq, heads, batch), dim3(64), 0, s, q, k, v, out, nq, nk, heads);
     else if (hd == 32) hipLaunchKernelGGL((mha32_kernel<32, 1>), dim3(nq, heads, batch), dim3(64), 0, s, q, k, v, out, nq, nk, heads);
     else return fail("mha32: head_dim=%d not built (16, 32)", hd);
