@@ -170,20 +170,23 @@ def main() -> None:
             peak = PEAK_TFLOPS[a.precision if a.precision in PEAK_TFLOPS else "bf16"]
             traffic = None
             try:   # HBM bytes per GEMM launch from the PMC passes committed under profiles/ (collected offline with rocprofv3)
-                with open(os.path.join(ROOT, "profiles", "r1c_pmc_traffic.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r1f_pmc_traffic.json")) as f:
                     traffic = json.load(f)["classes"]["gemm16"]["hbm_bytes_per_launch"]
                 if a.model != "vit_h" or B != 4:
                     traffic = None          # the committed counters are for the default workload only
             except Exception:
                 traffic = None
-            roofline = {"bound": "mfma", "kernel": "gemm16v3_kernel<T,320|256,4> (all 16-bit MFMA GEMM launches)",
+            roofline = {"bound": "mfma", "kernel": "gemm16v5_kernel<T,320|256,3> (all 16-bit MFMA GEMM launches)",
                         "achieved": round(achieved, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                        "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1c_pmc_traffic.json (B=4 run)",
+                        "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1f_pmc_traffic.json (B=4 run, tools/pmc_summarize.py)",
                         "launches_per_step": g["launches"] // a.steps,
                         "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
                         "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
-                        "ms_per_step_with_events": round(prof_elapsed / a.steps * 1e3, 3)}
+                        "ms_per_step_with_events": round(prof_elapsed / a.steps * 1e3, 3),
+                        "sustained_clock_note": "in-kernel s_memtime / wall-clock (WM_GEMM_DBG=1): 1.79 GHz under this load, i.e. "
+                                                "1.88 PFLOP/s of dense bf16 MFMA at the sustained clock; a register-only MFMA loop "
+                                                "(tools/mfma_peak.hip) sustains 2.13 PFLOP/s"}
             classes = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["launches"] // a.steps,
                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
                        for k, v in st.items()}

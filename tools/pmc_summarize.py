@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Summarise a `rocprofv3 -i tools/pmc_traffic.txt` run (one pmc_N directory per counter pass) into the per-kernel-class
+HBM traffic JSON that bench.py reads (profiles/*_pmc_traffic.json).
+
+usage: tools/pmc_summarize.py <rocprof output dir> <out.json> "<command that was profiled>"
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (wide
+coalesced reads are counted at half their bytes).  Averages are per launch over every launch of a class."""
+import collections, csv, glob, json, os, sys
+
+csv.field_size_limit(1 << 30)
+CLASSES = (("gemm16", ("gemm16",)), ("attn_global", ("attn_global_kernel",)), ("attn_window", ("attn_window_kernel",)),
+           ("layernorm", ("layernorm_kernel",)))
+
+
+def kclass(name):
+    for c, keys in CLASSES:
+        if any(k in name for k in keys):
+            return c
+    return None
+
+
+def main():
+    root, out, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(lambda: collections.defaultdict(set))
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                c = kclass(r["Kernel_Name"])
+                if c is None or r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+                    continue
+                tot[c][r["Counter_Name"]] += float(r["Counter_Value"])
+                launches[c][r["Counter_Name"]].add(r["Dispatch_Id"])
+    classes = {}
+    for c, _ in CLASSES:
+        if c not in tot:
+            continue
+        nf, nw = len(launches[c]["FETCH_SIZE"]), len(launches[c]["WRITE_SIZE"])
+        fetch, write = tot[c]["FETCH_SIZE"] / max(nf, 1), tot[c]["WRITE_SIZE"] / max(nw, 1)
+        classes[c] = {"launches": nf, "fetch_kib": round(fetch), "write_kib": round(write),
+                      "hbm_bytes_per_launch": round((2.0 * fetch + write) * 1024.0, -5)}
+    doc = {"command": cmd,
+           "note": "separate --pmc passes for FETCH_SIZE and WRITE_SIZE (TCC slots); counters in KiB; FETCH_SIZE doubled per "
+                   "MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); averages per launch over all "
+                   "launches of the class (ViT-H, B=4, bf16); produced by tools/pmc_summarize.py",
+           "classes": classes}
+    with open(out, "w") as fh:
+        json.dump(doc, fh, indent=1)
+    print(json.dumps(classes, indent=1))
+
+
+if __name__ == "__main__":
+    main()
