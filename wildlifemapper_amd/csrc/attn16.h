@@ -45,6 +45,12 @@ template <int HD> struct AttnGeom {
     static constexpr int NKS = HD / 16;                         // QK^T k-steps
     static constexpr int NDT = (HD + 31) / 32;                  // 32-row O^T tiles
     static constexpr int CH = HD / 8;                           // 16-byte chunks per row
+    // HD = 80: the last 32-row O^T tile has 16 spare rows.  The V image's pad column HD is set to 1.0 once, so row HD
+    // of O^T = sum_k P[k][q] = the softmax denominator, from the matrix pipe instead of 32 v_add per tile (and it is
+    // the sum of exactly the rounded P values the numerator uses).  Lane (c, h = 0) holds it in o[NDT-1][LSUM_R].
+    static constexpr bool LSUM_IN_O = (HD % 32) != 0;
+    static constexpr int LSUM_R = ((HD % 32) / 8) * 4;
+    static_assert(!LSUM_IN_O || (HD % 8) == 0, "pad column must fall on accumulator register LSUM_R of half 0");
 };
 
 template <class T>
@@ -125,7 +131,7 @@ __device__ __forceinline__ void softmax_pv(SoftmaxState<AttnGeom<HD>::NDT>& st, 
         for (int r = 0; r < 16; ++r) {
             const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][r], c1, off));
             s[t][r] = pv;
-            ls += pv;
+            if constexpr (!G::LSUM_IN_O) ls += pv;      // else: row HD of O^T accumulates the sum (V pad column = 1)
         }
     st.l += ls;
 
@@ -163,12 +169,24 @@ __device__ __forceinline__ void qk_tile(f32x16 (&s)[NT], const typename T::vec8 
         }
 }
 
+// Set the pad column HD of `rows` V rows (stride VS) to 1.0 (see AttnGeom::LSUM_IN_O).
+template <class T, int HD>
+__device__ __forceinline__ void v_pad_ones(char* sV, int rows, int tid, int nthreads) {
+    using G = AttnGeom<HD>;
+    if constexpr (G::LSUM_IN_O) {
+        const typename T::elem one = T::from_f32(1.0f);
+        for (int r = tid; r < rows; r += nthreads) *(typename T::elem*)(sV + r * G::VS + HD * 2) = one;
+    }
+}
+
 // Normalise and store O^T: lane (c = lane&31, h) holds dims 32dt + (r&3) + 8(r>>2) + 4h of query c.
 template <class T, int HD>
 __device__ __forceinline__ void store_out(SoftmaxState<AttnGeom<HD>::NDT>& st, u16* out_row, int lane, bool valid) {
     using G = AttnGeom<HD>;
     const int h = lane >> 5;
-    const float l = st.l + __shfl_xor(st.l, 32, 64);
+    float l;
+    if constexpr (G::LSUM_IN_O) l = __shfl(st.o[G::NDT - 1][G::LSUM_R], lane & 31, 64);
+    else l = st.l + __shfl_xor(st.l, 32, 64);
     const float inv = 1.0f / l;
     if (!valid) return;
 #pragma unroll
@@ -312,17 +330,29 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
     constexpr int PER = (NCH + 255) / 256;
     s16x8 kreg[PER], vreg[PER];
 
-    auto issue = [&](int tile) {
+    // per-thread source pointers of the staging chunks, advanced by one tile per issue (no per-tile address math)
+    const u16* kp[PER];
+    const u16* vp[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = min(tid + i * 256, NCH - 1);
+        kp[i] = kb + (size_t)(e / G::CH) * p.k_stride + (e % G::CH) * 8;
+        vp[i] = vb + (size_t)(e / G::CH) * p.v_stride + (e % G::CH) * 8;
+    }
+    const size_t k_step = (size_t)64 * p.k_stride, v_step = (size_t)64 * p.v_stride;
+    auto issue = [&](int) {                          // tiles are requested in order
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int e = tid + i * 256;
-            if (e < NCH) {
-                const int key = e / G::CH, ch = e % G::CH;
-                kreg[i] = *(const s16x8*)(kb + (size_t)(tile * 64 + key) * p.k_stride + ch * 8);
-                vreg[i] = *(const s16x8*)(vb + (size_t)(tile * 64 + key) * p.v_stride + ch * 8);
+            if (tid + i * 256 < NCH) {
+                kreg[i] = *(const s16x8*)kp[i];
+                vreg[i] = *(const s16x8*)vp[i];
             }
+            kp[i] += k_step;
+            vp[i] += v_step;
         }
     };
+    v_pad_ones<T, HD>(sKV + L::K_BYTES, 64, tid, 256);
+    v_pad_ones<T, HD>(sKV + (L::K_BYTES + L::V_BYTES) + L::K_BYTES, 64, tid, 256);
     auto commit = [&](int buf) {
         char* sK = sKV + buf * (L::K_BYTES + L::V_BYTES);
         char* sV = sK + L::K_BYTES;
@@ -502,6 +532,7 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
     prefetch_kv(item);
     load_q(qf, item);
     commit_kv();
+    v_pad_ones<T, HD>(sV, L::NKEY, tid, NTHR);            // the staging never touches the pad columns again
     __syncthreads();
 
     while (true) {
