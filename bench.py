@@ -184,9 +184,9 @@ def main() -> None:
                         "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
                         "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
                         "ms_per_step_with_events": round(prof_elapsed / a.steps * 1e3, 3),
-                        "sustained_clock_note": "in-kernel s_memtime / wall-clock (WM_GEMM_DBG=1): 1.79 GHz under this load, i.e. "
-                                                "1.88 PFLOP/s of dense bf16 MFMA at the sustained clock; a register-only MFMA loop "
-                                                "(tools/mfma_peak.hip) sustains 2.13 PFLOP/s"}
+                        "sustained_clock_note": "power-limited: in-kernel s_memtime / wall clock (WM_GEMM_DBG=1) reads ~1.5 GHz at the "
+                                                "31st GEMM of a step (1.79 GHz isolated, 1.34 GHz in a GEMM-only loop), i.e. ~1.57 "
+                                                "PFLOP/s of dense bf16 MFMA at the sustained clock; DESIGN.md section 5"}
             classes = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["launches"] // a.steps,
                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
                        for k, v in st.items()}

@@ -90,6 +90,41 @@ def test_gemm16_inplace_residual():
     assert G.rel_l2(x, want) < 1e-5
 
 
+@pytest.mark.parametrize("N", [640, 512])                     # 256x320 and 256x256 tiles (gemm16_v5.h)
+@pytest.mark.parametrize("outs", ["f32", "both", "16"])
+def test_gemm16_v5_residual_paths(N, outs):
+    """The staggered kernel's residual epilogue (residual tile by LDS-DMA, 8 passes): in place as the encoder uses it
+    (residual == out, image_encoder.py:200-203), with both outputs, and with a 16-bit output only."""
+    M, K = 768, 256
+    a = G.to16(torch.randn(M, K, device=G.dev()), "bf16")
+    w = G.to16(torch.randn(N, K, device=G.dev()) / 16, "bf16")
+    bias = torch.randn(N, device=G.dev())
+    x = torch.randn(M, N, device=G.dev())
+    want = x + a.float() @ w.float().t() + bias
+    from wildlifemapper_amd import _native as Nn
+    o16 = torch.empty(M, N, device=G.dev(), dtype=torch.bfloat16) if outs != "f32" else None
+    o32 = x if outs != "16" else None                        # in place
+    Nn.check(Nn.lib().wm_op_gemm16(Nn.ptr(a), Nn.ptr(w), Nn.ptr(bias), Nn.ptr(x), 0, Nn.ptr(o32), Nn.ptr(o16), M, N, K, 0, 0, G.sp()))
+    if o32 is not None:
+        assert G.rel_l2(o32, want) < 1e-5
+    if o16 is not None:
+        assert G.rel_l2(o16.float(), want) < OUT16_TOL["bf16"]
+
+
+def test_gelu_fast_accuracy():
+    """The 16-bit GEMM epilogue's GELU (degree-3/3 rational erf, wm_common.h) against the exact-erf form, fp32 output:
+    C[m][n] = a[m][0] * w[n][0] with power-of-two row scales sweeps x over [-9, 9] exactly."""
+    M, N, K = 256, 640, 64
+    a = torch.zeros(M, K, device=G.dev())
+    w = torch.zeros(N, K, device=G.dev())
+    a[:, 0] = torch.tensor([2.0 ** (-(i % 4)) for i in range(M)], device=G.dev())
+    w[:, 0] = torch.linspace(-9.0, 9.0, N, device=G.dev())
+    a16, w16 = G.to16(a, "fp16"), G.to16(w, "fp16")
+    o32, _ = G.gemm16(a16, w16, act=1, prec="fp16")
+    x = a16.float() @ w16.float().t()
+    assert (o32 - O.gelu_erf(x)).abs().max().item() < 2e-5
+
+
 def test_gemm16_rejects_ragged():
     a = G.to16(torch.randn(100, 64, device=G.dev()), "bf16")
     w = G.to16(torch.randn(128, 64, device=G.dev()), "bf16")

@@ -249,9 +249,9 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     if (stagger > 0 && grid > 256) const_cast<Gemm16Args&>(a).conv_c = stagger;
     if constexpr (BN == 320 && NSLOT == 3) {
         static const bool dbg = getenv("WM_GEMM_DBG") != nullptr;          // dev: in-kernel interval timing of workgroup 0
-        static int dbg_left = 3;
-        if (dbg && dbg_left > 0) {
-            --dbg_left;
+        static int dbg_count = 0;          // instrument the 1st and, after a run of back-to-back launches, the 31st
+        if (dbg) ++dbg_count;
+        if (dbg && (dbg_count == 1 || dbg_count == 31)) {
             static unsigned* buf = nullptr;
             const size_t bytes = 512 + (size_t)grid * 40;
             if (!buf) HIP_TRY(hipMalloc((void**)&buf, 512 + 8192 * 40));
