@@ -333,8 +333,16 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
     const int mode = gemm_mode();
     if (M % 256 == 0 && mode != 1) {
         if (mode == 0 && K / 32 >= 2) {      // staggered wave groups (gemm16_v5.h)
-            if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320>(h, s, a)), (launch_gemm16v5_t<FP16, 320>(h, s, a)));
-            if (N % 256 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 256>(h, s, a)), (launch_gemm16v5_t<FP16, 256>(h, s, a)));
+            // Few tiles (one or two image tiles per call): the half-width 256 x 160 / 128 kernel fills more CUs.  Cost
+            // model from tools/gemm_bench.py --batch 1: rounds of 256 workgroups x (1.0 | 0.6) per tile.
+            auto prefer_half = [&](int bn) {
+                const long t = (long)(M / 256) * (N / bn);
+                return (double)((2 * t + 255) / 256) * 0.6 < (double)((t + 255) / 256);
+            };
+            if (N % 320 == 0 && !prefer_half(320)) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320>(h, s, a)), (launch_gemm16v5_t<FP16, 320>(h, s, a)));
+            if (N % 320 != 0 && N % 256 == 0 && !prefer_half(256)) return WM_BY_PREC((launch_gemm16v5_t<BF16, 256>(h, s, a)), (launch_gemm16v5_t<FP16, 256>(h, s, a)));
+            if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v2_t<BF16, 160>(h, s, a)), (launch_gemm16v2_t<FP16, 160>(h, s, a)));
+            if (N % 256 == 0) return WM_BY_PREC((launch_gemm16v2_t<BF16, 128>(h, s, a)), (launch_gemm16v2_t<FP16, 128>(h, s, a)));
         }
         if (mode == 0 || mode == 4) {
             if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v3_t<BF16, 320, 4>(h, s, a)), (launch_gemm16v3_t<FP16, 320, 4>(h, s, a)));
