@@ -15,7 +15,8 @@
 //
 // so each SIMD always has one wave in its MFMA phase while the other reads / issues DMA
 // (cdna_hip_programming.md: the 8-phase template's `if (wr == 1) s_barrier`; MI355X_MICROARCH.md "Two waves
-// per SIMD", item 9).  Ring, swizzle, counted vmcnt, tile order and epilogue are gemm16_v3.h's:
+// per SIMD", item 9).  Ring, swizzle, counted vmcnt and tile order are gemm16_v3.h's; the epilogue (below, at its
+// code) goes through LDS so that global accesses are row-contiguous, and brings an fp32 residual in by LDS-DMA:
 //   RAW  a wave waits for its own pieces of step s (vmcnt) before X_s; every read of slot s follows X_s.
 //   WAR  slot (s+2)%3 = (s-1)%3 is overwritten after X_s: waves 0-3 read it before Y_s-1, waves 4-7 after
 //        Y_s-1 and drain those reads (lgkmcnt(0)) before they arrive at X_s.
@@ -25,8 +26,9 @@
 
 namespace wm {
 
-// DBG (dev only, WM_GEMM_DBG=1): waves 0 and 4 of workgroup 0 record s_memtime at six marks of K-steps 8..17 into
-// p.zero_page (2 x 64 u32).
+// DBG (dev only, WM_GEMM_DBG=1, see launch_gemm16v5_t): waves 0 and 4 of workgroup 0 record s_memtime at six marks of
+// K-steps 8..17, every workgroup its wall-clock entry / first barrier / loop end / stores-acknowledged stamps, into
+// p.zero_page.  The instrumented instance is a separate kernel; the product instance carries none of it.
 template <class T, int BN, int NSLOT = 3, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     using C = G3<BN, 4>;
@@ -36,10 +38,6 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long wt0 = 0, wt1 = 0, wt2 = 0, mt1 = 0, mt2 = 0, we[6] = {0, 0, 0, 0, 0, 0};
     if constexpr (DBG) wt0 = wall_clock64();
-    if (p.conv_c > 0 && blockIdx.x < 256) {               // experiment: de-phase the first round (conv_c = span in 10 ns units)
-        const unsigned long long until = wall_clock64() + (unsigned long long)(((blockIdx.x * 37u) & 15u) * (unsigned)p.conv_c / 16u);
-        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
-    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;               // wave group = wr: rows 0-127 / 128-255

@@ -245,8 +245,6 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     const int grid = (a.M / 256) * (a.N / BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
-    static const int stagger = getenv("WM_GEMM_STAGGER_US") ? (int)(atof(getenv("WM_GEMM_STAGGER_US")) * 100) : 0;
-    if (stagger > 0 && grid > 256) const_cast<Gemm16Args&>(a).conv_c = stagger;
     if constexpr (BN == 320 && NSLOT == 3) {
         static const bool dbg = getenv("WM_GEMM_DBG") != nullptr;          // dev: in-kernel interval timing of workgroup 0
         static int dbg_count = 0;          // instrument the 1st and, after a run of back-to-back launches, the 31st
