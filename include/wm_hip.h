@@ -53,8 +53,14 @@ typedef struct wm_config {
     int32_t global_attn_indexes[WM_MAX_GLOBAL];
     int32_t max_batch;                        /* tiles per call the workspace is sized for */
     int32_t precision;                        /* WM_PREC_* */
-    int32_t reserved[4];
+    int32_t flags;                            /* WM_FLAG_* engine options, 0 = defaults */
+    int32_t reserved[3];
 } wm_config;
+
+/* wm_config.flags.  WM_CFG_FUSE_LN: the two residual GEMMs of a transformer block also produce the LayerNorm that
+ * follows them (see wm_op_gemm16_ln) where the batch allows; results are bit-identical either way.  Off by default:
+ * measured +0.5 % tiles/s on ViT-H B=4 (the GEMMs are power-limited).  Also: env WM_LN_FUSE=1. */
+#define WM_CFG_FUSE_LN 1
 
 typedef struct wm_handle wm_handle;
 
@@ -170,6 +176,16 @@ int wm_op_cvt_16_to_f32(const void* in_dev, float* out_dev, int64_t n, int preci
 int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* bias_dev,
                  const float* residual_dev, int res_mod, float* out_f32_dev, void* out_16_dev,
                  int M, int N, int K, int act, int precision, void* stream);
+
+/* The transformer block's two residual updates fused with the LayerNorm that follows them
+ * (image_encoder.py:200-203: x = shortcut + attn(...), then norm2(x); x = x + mlp(...), then the next block's norm1):
+ * out_f32 = residual + A W^T + bias (residual may alias out_f32) and out_16 = LayerNorm(out_f32 rows; gamma, beta, eps).
+ * Fails if the shape cannot be fused (M % 256, N % 320 or 256, at most 4 column tiles, enough tiles to fill the chip,
+ * every row block's workgroups co-resident); wm_encoder_forward then uses wm_op_gemm16 + wm_op_layernorm, whose
+ * 16-bit-only form computes the statistics the same way, so the results are bit-identical.  Synchronises the stream. */
+int wm_op_gemm16_ln(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev,
+                    float* out_f32_dev, void* out_16_dev, const float* gamma_dev, const float* beta_dev, float eps,
+                    int M, int N, int K, int precision, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution without bias over a 64x64 token grid as an implicit GEMM (no im2col
  * buffer): the second neck conv, image_encoder.py:113-119.  a [B,64,64,c_in] NHWC 16-bit,

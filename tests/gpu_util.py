@@ -48,6 +48,18 @@ def gemm16(a16, w16, bias=None, residual=None, res_mod=0, act=0, prec="bf16", wa
     return o32, o16
 
 
+def gemm16_ln(a16, w16, bias, residual, gamma, beta, eps, prec="bf16"):
+    """x = residual + a w^T + bias (in a copy of residual), LayerNorm(x) in 16 bits.  Returns (x32, ln16)."""
+    code, dt = PRECS[prec]
+    M, K = a16.shape
+    Nn = w16.shape[0]
+    x = residual.clone()
+    o16 = torch.empty((M, Nn), device=a16.device, dtype=dt)
+    N.check(N.lib().wm_op_gemm16_ln(N.ptr(a16), N.ptr(w16), N.ptr(bias), N.ptr(x), N.ptr(x), N.ptr(o16), N.ptr(gamma), N.ptr(beta),
+                                    eps, M, Nn, K, code, sp()))
+    return x, o16
+
+
 def gemm32(a, w, bias=None, residual=None, act=0):
     M, K = a.shape
     Nn = w.shape[0]

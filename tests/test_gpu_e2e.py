@@ -216,6 +216,29 @@ def test_dropin_modules_and_batch_invariance():
     assert set(res[0]) == {"scores", "labels", "boxes"}
 
 
+def test_fused_layernorm_option_is_bit_identical():
+    """wm_config.flags & WM_CFG_FUSE_LN (residual GEMMs also emit the following LayerNorm, row statistics exchanged
+    between workgroups): same bits as the default path, also for a batch that cannot fuse."""
+    m, _ = _model("vit_b", "bf16")
+    x = torch.from_numpy(synth.make_batch(20, 4)).to(G.dev())          # 4 tiles: 64 x 3 = 192 workgroups -> fusable
+    hub = m._hub
+    base = m(NestedTensor(x, None), None)
+    base1 = m(NestedTensor(x[2:3].contiguous(), None), None)
+    hub.fuse_ln = True
+    hub.close()                                                        # next forward re-creates the handle with the flag
+    try:
+        fused = m(NestedTensor(x, None), None)
+        fused1 = m(NestedTensor(x[2:3].contiguous(), None), None)      # 1 tile: too few workgroups, separate kernels
+        st = hub.profile_read() if hasattr(hub, "profile_read") else None   # raises if a fused launch timed out
+    finally:
+        hub.fuse_ln = False
+        hub.close()
+    assert torch.equal(fused["pred_logits"], base["pred_logits"]) and torch.equal(fused["pred_boxes"], base["pred_boxes"])
+    assert torch.equal(fused1["pred_logits"], base1["pred_logits"])
+    assert torch.equal(fused1["pred_logits"][0], fused["pred_logits"][2])
+    del st
+
+
 def test_evaluate_harness(golden_dir):
     """inference.evaluate (inference.py:30-89): loader of (NestedTensor, targets) -> per-image detections,
     checked against PostProcess of the golden logits."""

@@ -16,12 +16,13 @@ PREC_BY_NAME = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16}
 NUM_QUERIES, NUM_LOGITS = 51, 8
 KCLASS_NAMES = ("gemm16", "attn_window", "attn_global", "layernorm", "other")
 FLAG_CONF, FLAG_SCORE, FLAG_NMS = 1, 2, 4
+CFG_FUSE_LN = 1
 
 
 class WmConfig(C.Structure):
     _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32),
                 ("num_global", C.c_int32), ("global_attn_indexes", C.c_int32 * 8),
-                ("max_batch", C.c_int32), ("precision", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("max_batch", C.c_int32), ("precision", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class WmBoxRecord(C.Structure):
@@ -56,6 +57,7 @@ SYMBOLS = {
     "wm_op_cvt_f32_to_16": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_cvt_16_to_f32": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_gemm16": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm_op_gemm16_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
     "wm_op_conv3x3_16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "wm_op_gemm32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "wm_op_layernorm": (_I, [_P, _P, _P, _F, _P, _P, _L, _I, _I, _P]),

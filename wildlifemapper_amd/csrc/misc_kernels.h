@@ -63,6 +63,49 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// The transformer blocks' LayerNorm with the column-tiled statistics of wm_common.h (ln_partial16 / ln_combine): the
+// same arithmetic, operation for operation, as the LayerNorm fused into the residual GEMMs (gemm16_v5.h), which only
+// some batch sizes can use -- a tile's result must not depend on its batch neighbours.  One wave per row, 16-lane
+// group k owns column tile k (C = TN * BN, TN <= 4), 16-bit output.  grid (rows / 4), 256 threads.
+// ---------------------------------------------------------------------------
+template <class T, int BN>
+__global__ __launch_bounds__(256) void layernorm_tiled_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, u16* __restrict__ out16,
+                                                              int64_t rows, int C) {
+    constexpr int CPT = BN / 64;                       // 16-byte chunks per lane (BN / 4 per tile over 16 lanes)
+    const int lane = threadIdx.x & 63, k = lane >> 4, l16 = lane & 15;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int ntile = C / BN;
+    const bool live = k < ntile;
+    const float* xr = x + row * C + k * BN;
+    f32x4 v[CPT];
+#pragma unroll
+    for (int kk = 0; kk < CPT; ++kk) v[kk] = live ? *(const f32x4*)(xr + (l16 + 16 * kk) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float pm, pq;
+    ln_partial16<CPT>(v, 1.0f / BN, pm, pq);
+    float mk[8], qk[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mk[i] = i < 4 ? __shfl(pm, i * 16, 64) : 0.f;
+        qk[i] = i < 4 ? __shfl(pq, i * 16, 64) : 0.f;
+    }
+    float rstd;
+    const float mean = ln_combine(mk, qk, ntile, (float)BN, (float)C, eps, rstd);
+    if (!live) return;
+#pragma unroll
+    for (int kk = 0; kk < CPT; ++kk) {
+        const int c0 = k * BN + (l16 + 16 * kk) * 4;
+        const f32x4 g = *(const f32x4*)(gamma + c0);
+        const f32x4 b = *(const f32x4*)(beta + c0);
+        typename T::vec4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = T::from_f32(ln_apply(v[kk][j], mean, rstd, g[j], b[j]));
+        *(typename T::vec4*)(out16 + row * C + c0) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Patch gather for the 16x16/s16 embeds (image_encoder.py:409-417, 442-450):
 // x (B,Cin,1024,1024) fp32 -> P [B*4096, Cin*256] 16-bit, column = c*256 + ky*16 + kx
 // (Conv2d weight order).  One thread per 4 consecutive kx.

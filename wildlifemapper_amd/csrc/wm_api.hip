@@ -105,8 +105,19 @@ struct Profiler {
 
 }  // namespace
 
+// Workspace of the fused residual GEMM + LayerNorm (gemm16_v5.h, LNF instance): per-row partial statistics and the row
+// blocks' arrival counters; counter_base[0] is the "a partner never arrived" flag.  The counters only ever grow: a
+// launch's target is tiles_N * epoch, so the epoch restarts (with a memset) whenever the geometry changes.  One per
+// handle (launches of one handle are stream-ordered), plus one for the handle-less single-op entry.
+struct LnFuseState {
+    float* stats = nullptr;       // [M][ntile][2]
+    int* counter_base = nullptr;  // [1 + mtiles]
+    size_t stats_floats = 0;
+    int counters = 0, epoch = 0, geom = -1;
+};
 struct wm_handle {
     wm_config cfg{};
+    LnFuseState lnf;
     int device = 0;
     int D = 0, depth = 0, heads = 0, hd = 0, prec = 0, maxB = 0;
     bool is_global[64] = {};
@@ -309,6 +320,129 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     return 0;
 }
 
+// ---- fused residual GEMM + LayerNorm (gemm16_v5.h, LNF instance) ----
+static LnFuseState g_lnf;
+
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+// Which column tile the fused kernel would use, or 0 if this shape must keep the separate LayerNorm kernel: every
+// workgroup of a row block has to be resident together, i.e. the grid fits the chip, or the XCD remap hands each XCD
+// whole groups of 8 row blocks (then a round never splits a row block).
+static int ln_fuse_bn(int M, int N, int K) {
+    if (M % 256 || K % 32 || K / 32 < 2) return 0;
+    const int bn = N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : 0);
+    if (!bn) return 0;
+    const int tn = N / bn, nwg = (M / 256) * tn;
+    if (tn > 4) return 0;                                  // layernorm_tiled_kernel (the unfused twin) holds 4 column tiles
+    if ((double)((2L * nwg + 255) / 256) * 0.6 < (double)((nwg + 255) / 256)) return 0;   // too few tiles: launch_gemm16 prefers the half-width kernel
+    if (nwg <= num_cus()) return bn;
+    if (nwg % 8 == 0 && (nwg / 8) % (G16_GROUP_M * tn) == 0 && (M / 256) % G16_GROUP_M == 0) return bn;
+    return 0;
+}
+
+template <class T16, int BN>
+int launch_gemm16v5_ln_t(wm_handle* h, hipStream_t s, Gemm16Args a) {
+    using G = G3<BN, 4>;
+    constexpr int LDS = 3 * G::STAGE + 32 * BN * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v5_kernel<T16, BN, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    LnFuseState& g_lnf = h ? h->lnf : ::g_lnf;
+    const int mtiles = a.M / 256, tn = a.N / BN;
+    const size_t need = (size_t)a.M * tn * 2;
+    if (need > g_lnf.stats_floats) {
+        if (g_lnf.stats) HIP_TRY(hipFree(g_lnf.stats));
+        g_lnf.stats = nullptr; g_lnf.stats_floats = 0;
+        HIP_TRY(hipMalloc((void**)&g_lnf.stats, need * 4));
+        g_lnf.stats_floats = need;
+    }
+    if (mtiles + 1 > g_lnf.counters) {
+        if (g_lnf.counter_base) HIP_TRY(hipFree(g_lnf.counter_base));
+        g_lnf.counter_base = nullptr; g_lnf.counters = 0;
+        HIP_TRY(hipMalloc((void**)&g_lnf.counter_base, (size_t)(mtiles + 1) * 4));
+        g_lnf.counters = mtiles + 1;
+        g_lnf.geom = -1;
+    }
+    const int geom = mtiles * 16 + tn;
+    if (geom != g_lnf.geom || g_lnf.epoch > (1 << 26)) {
+        HIP_TRY(hipMemsetAsync(g_lnf.counter_base, 0, (size_t)g_lnf.counters * 4, s));
+        g_lnf.geom = geom;
+        g_lnf.epoch = 0;
+    }
+    a.ln_stats = g_lnf.stats;
+    a.ln_counter = g_lnf.counter_base + 1;
+    a.ln_epoch = ++g_lnf.epoch;
+    const int grid = mtiles * tn;
+    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
+               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + 10.0 * a.M * a.N);
+    static const bool timeline = getenv("WM_LNF_TIMELINE") != nullptr;       // dev: per-workgroup stamps of the fused epilogue
+    static int tl_count = 0;
+    if (timeline && ++tl_count == 12) {
+        static unsigned long long* buf = nullptr;
+        if (!buf) HIP_TRY(hipMalloc((void**)&buf, 8192 * 32));
+        if (grid > 8192) return fail("timeline grid");
+        a.zero_page = (const u16*)buf;
+        hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, true>), dim3(grid), dim3(512), LDS, s, a);
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned long long> hb((size_t)grid * 4);
+        HIP_TRY(hipMemcpy(hb.data(), buf, hb.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int i = 0; i < grid; ++i) t0 = std::min(t0, hb[i * 4]);
+        double a1 = 0, a2 = 0, a3 = 0, m1 = 0, m3 = 0, mx_end = 0, mn1 = 1e30;
+        for (int i = 0; i < grid; ++i) {
+            const double passA = (hb[i * 4] - t0) * 0.01, pub = (hb[i * 4 + 1] - hb[i * 4]) * 0.01, wait = (hb[i * 4 + 2] - hb[i * 4 + 1]) * 0.01,
+                         passB = (hb[i * 4 + 3] - hb[i * 4 + 2]) * 0.01;
+            a1 += pub; a2 += wait; a3 += passB; m1 = std::max(m1, passA); mn1 = std::min(mn1, passA); m3 = std::max(m3, wait);
+            mx_end = std::max(mx_end, (hb[i * 4 + 3] - t0) * 0.01);
+        }
+        fprintf(stderr, "[gemm16v5 LNF timeline] M=%d N=%d K=%d: pass A ends spread over %.2f us; publish avg %.2f us; wait avg %.2f max %.2f us; "
+                "pass B avg %.2f us; last workgroup done %.2f us after the first pass-A end\n", a.M, a.N, a.K, m1 - mn1, a1 / grid, a2 / grid, m3, a3 / grid, mx_end);
+        return 0;
+    }
+    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, true>), dim3(grid), dim3(512), LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// out32 = residual + A W^T + bias (residual may alias out32), out16 = LayerNorm(out32 rows).  Returns 1 (and launches
+// nothing) when the shape cannot be fused; the caller then runs the GEMM and the LayerNorm kernel separately.
+int launch_gemm16_ln(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias, const float* res,
+                     float* out32, void* out16, const float* gamma, const float* beta, float eps, int M, int N, int K) {
+    static const bool mode0 = !getenv("WM_GEMM_MODE") || atoi(getenv("WM_GEMM_MODE")) == 0;
+    const bool off = h && !(h->cfg.flags & WM_CFG_FUSE_LN);          // engine: opt-in; the single-op entry always fuses
+    const int bn = ln_fuse_bn(M, N, K);
+    if (off || !mode0 || !bn || !res || !out32 || !out16 || !gamma || !beta) return 1;
+    static const int dbg_bits = getenv("WM_LNF_DBG") ? atoi(getenv("WM_LNF_DBG")) : 0;     // timing experiments: 256 no LN stores, 1024 no wait
+    Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, 0, ACT_NONE | dbg_bits, 0, nullptr, gamma, beta, eps, nullptr, nullptr, 0};
+    if (bn == 320) return prec == WM_PREC_FP16 ? launch_gemm16v5_ln_t<FP16, 320>(h, s, a) : launch_gemm16v5_ln_t<BF16, 320>(h, s, a);
+    return prec == WM_PREC_FP16 ? launch_gemm16v5_ln_t<FP16, 256>(h, s, a) : launch_gemm16v5_ln_t<BF16, 256>(h, s, a);
+}
+
+// 1 if some fused launch gave up waiting for a partner workgroup (results of that launch are wrong); clears the flag
+int ln_fuse_check(wm_handle* h, hipStream_t s) {
+    LnFuseState& g_lnf = h ? h->lnf : ::g_lnf;
+    if (!g_lnf.counter_base) return 0;
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, g_lnf.counter_base, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (flag) {
+        HIP_TRY(hipMemsetAsync(g_lnf.counter_base, 0, 4, s));
+        return fail("fused GEMM + LayerNorm: a workgroup timed out waiting for its row-block partners");
+    }
+    return 0;
+}
+
 // fraction of the last round of workgroup slots that is filled
 static double round_eff(long tiles, long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); }
 
@@ -410,6 +544,25 @@ int launch_layernorm(wm_handle* h, hipStream_t s, int prec, const float* x, cons
         default: return fail("layernorm: C=%d", C);
     }
 #undef LN_CASE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// LayerNorm of the transformer blocks (norm1 / norm2, 16-bit output): column-tiled statistics, bit-identical to the
+// LayerNorm fused into the residual GEMMs (launch_gemm16_ln), so results do not depend on which of the two ran.
+int launch_layernorm_block(wm_handle* h, hipStream_t s, int prec, const float* x, const float* g, const float* b, float eps,
+                           void* out16, int64_t rows, int C) {
+    const int bn = C % 320 == 0 ? 320 : (C % 256 == 0 ? 256 : 0);
+    if (!bn || C / bn > 4) return launch_layernorm(h, s, prec, x, g, b, eps, nullptr, out16, rows, C);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    Bracket br(h, s, WM_KCLASS_LAYERNORM, 0.0, (double)rows * C * 6.0);
+    if (bn == 320) {
+        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((layernorm_tiled_kernel<FP16, 320>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
+        else hipLaunchKernelGGL((layernorm_tiled_kernel<BF16, 320>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
+    } else {
+        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((layernorm_tiled_kernel<FP16, 256>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
+        else hipLaunchKernelGGL((layernorm_tiled_kernel<BF16, 256>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -722,6 +875,8 @@ extern "C" int wm_destroy(wm_handle* h) {
     hipDeviceSynchronize();
     for (void* p : h->allocs) if (p) hipFree(p);
     if (h->tap_buf) hipFree(h->tap_buf);
+    if (h->lnf.stats) hipFree(h->lnf.stats);
+    if (h->lnf.counter_base) hipFree(h->lnf.counter_base);
     for (auto& e : h->prof.used) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : h->prof.pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete h;
@@ -901,20 +1056,38 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     WM_TRY(do_tap(h, s, -1, B));
 
     // ---- transformer blocks (image_encoder.py:188-204) ----
+    // x = x + proj(attn(norm1 x)); x = x + lin2(gelu(lin1(norm2 x))).  The two residual GEMMs also produce the following
+    // LayerNorm's output where the shape allows (launch_gemm16_ln returns 1 otherwise and the separate kernels run).
+    bool xn_ready = false;                                  // xn16 already holds norm1 of the current residual stream
     for (int i = 0; i < h->depth; ++i) {
         const std::string b = e + "blocks." + std::to_string(i) + ".";
-        WM_TRY(launch_layernorm(h, s, P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, nullptr, h->xn16, M, D));
+        if (!xn_ready)
+            WM_TRY(launch_layernorm_block(h, s, P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D));
         WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "attn.qkv.weight"), W32(h, b + "attn.qkv.bias"), nullptr, 0, nullptr,
                              h->qkv16, M, 3 * D, D, ACT_NONE));
         WM_TRY(launch_encoder_attention(h, s, P, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
                                         W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14));
-        WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
-                             h->resid, nullptr, M, D, D, ACT_NONE));
-        WM_TRY(launch_layernorm(h, s, P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, nullptr, h->xn16, M, D));
+        int r = launch_gemm16_ln(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, h->resid,
+                                 h->xn16, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, M, D, D);
+        if (r < 0) return r;
+        if (r == 1) {
+            WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
+                                 h->resid, nullptr, M, D, D, ACT_NONE));
+            WM_TRY(launch_layernorm_block(h, s, P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D));
+        }
         WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.bias"), nullptr, 0, nullptr,
                              h->hid16, M, 4 * D, D, ACT_GELU));
-        WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
-                             h->resid, nullptr, M, D, 4 * D, ACT_NONE));
+        xn_ready = false;
+        if (i + 1 < h->depth) {
+            const std::string nb = e + "blocks." + std::to_string(i + 1) + ".";
+            r = launch_gemm16_ln(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, h->resid,
+                                 h->xn16, W32(h, nb + "norm1.weight"), W32(h, nb + "norm1.bias"), 1e-6f, M, D, 4 * D);
+            if (r < 0) return r;
+            xn_ready = r == 0;
+        }
+        if (!xn_ready)
+            WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
+                                 h->resid, nullptr, M, D, 4 * D, ACT_NONE));
         WM_TRY(do_tap(h, s, i, B));
     }
 
@@ -1124,7 +1297,7 @@ extern "C" int wm_profile_read(wm_handle* h, wm_kclass_stat* out) {
     if (!h || !out) return fail("wm_profile_read: null argument");
     WM_TRY(prof_collect(h));
     for (int i = 0; i < WM_KCLASS_COUNT; ++i) out[i] = h->prof.acc[i];
-    return 0;
+    return ln_fuse_check(h, nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -1160,6 +1333,18 @@ extern "C" int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* b
     return launch_gemm16(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, bias_dev, residual_dev, res_mod, out_f32_dev, out_16_dev, M, N, K, act);
 }
 
+extern "C" int wm_op_gemm16_ln(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev,
+                               float* out_f32_dev, void* out_16_dev, const float* gamma_dev, const float* beta_dev, float eps,
+                               int M, int N, int K, int precision, void* stream) {
+    if (!a_dev || !w_dev || !residual_dev || !out_f32_dev || !out_16_dev || !gamma_dev || !beta_dev)
+        return fail("wm_op_gemm16_ln: null buffer");
+    const int r = launch_gemm16_ln(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, bias_dev, residual_dev, out_f32_dev, out_16_dev,
+                                   gamma_dev, beta_dev, eps, M, N, K);
+    if (r == 1) return fail("wm_op_gemm16_ln: M=%d N=%d K=%d cannot be fused (M %% 256, N %% 320 or 256, <= 8 column tiles, row blocks co-resident)", M, N, K);
+    if (r) return r;
+    return ln_fuse_check(nullptr, (hipStream_t)stream);
+}
+
 extern "C" int wm_op_conv3x3_16(const void* a_dev, const void* w_dev, float* out_dev, int batch, int c_out, int c_in, int precision,
                                void* stream) {
     return launch_conv3x3_16(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, out_dev, batch * 4096, c_out, c_in);
@@ -1172,6 +1357,8 @@ extern "C" int wm_op_gemm32(const float* a_dev, const float* w_dev, const float*
 
 extern "C" int wm_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, float* out_f32_dev,
                                void* out_16_dev, int64_t rows, int C, int precision, void* stream) {
+    if (!out_f32_dev && out_16_dev)      // the transformer blocks' form: column-tiled statistics (bit-identical to wm_op_gemm16_ln)
+        return launch_layernorm_block(nullptr, (hipStream_t)stream, precision, x_dev, gamma_dev, beta_dev, eps, out_16_dev, rows, C);
     return launch_layernorm(nullptr, (hipStream_t)stream, precision, x_dev, gamma_dev, beta_dev, eps, out_f32_dev, out_16_dev, rows, C);
 }
 

@@ -113,6 +113,52 @@ __device__ __forceinline__ f32x4 gelu_erf_fast4(f32x4 v) {
     return f32x4{a[0], a[1], b[0], b[1]};
 }
 
+// ---------------------------------------------------------------------------
+// LayerNorm statistics in column tiles (shared by the fused GEMM epilogue, gemm16_v5.h, and layernorm_tiled_kernel,
+// misc_kernels.h, so that both give bit-identical results whichever of them a batch size selects).  A row of N = TN * BN
+// columns is TN partials; a partial is owned by a 16-lane group, lane l16 holding the 16-byte chunks l16 + 16 kk:
+// two-pass (mean, M2) inside the partial, then Chan's combination of the TN equal-sized partials.
+// ---------------------------------------------------------------------------
+template <int CPT>
+__device__ __forceinline__ void ln_partial16(const f32x4 (&v)[CPT], float inv_bn, float& mean, float& m2) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < CPT; ++kk) s1 += (v[kk][0] + v[kk][1]) + (v[kk][2] + v[kk][3]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+    mean = s1 * inv_bn;
+    m2 = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < CPT; ++kk)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[kk][j] - mean;
+            m2 = fmaf(d, d, m2);
+        }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m2 += __shfl_xor(m2, o, 64);
+}
+// mk / qk: the partials' means and M2s (ntile <= 8 used); returns the row mean, sets rstd
+__device__ __forceinline__ float ln_combine(const float (&mk)[8], const float (&qk)[8], int ntile, float bn, float n, float eps, float& rstd) {
+    float msum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < ntile) msum += mk[i];
+    const float mean = msum / (float)ntile;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < ntile) {
+            const float d = mk[i] - mean;
+            m2 += fmaf(bn * d, d, qk[i]);
+        }
+    rstd = 1.0f / sqrtf(m2 / n + eps);
+    return mean;
+}
+__device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float g, float b) {
+    return fmaf((v - mean) * rstd, g, b);
+}
+
 // XCD-aware block remap (bijective for any grid size): blocks that share an XCD
 // (equal blockIdx % 8 under round-robin dispatch) get a contiguous range of
 // logical tile ids, so neighbouring tiles share operand panels in one L2.

@@ -29,6 +29,7 @@ class EngineHub:
         if self.precision not in N.PREC_BY_NAME:
             raise ValueError(f"unknown precision {self.precision!r} (bf16 | fp16)")
         self.max_batch = int(max_batch or os.environ.get("WM_MAX_BATCH", 0) or 0)
+        self.fuse_ln = os.environ.get("WM_LN_FUSE", "0") == "1"    # wm_config.flags & WM_CFG_FUSE_LN; set before the first forward
         self._handle: Optional[C.c_void_p] = None
         self._device: Optional[torch.device] = None
         self._sources: Dict[str, torch.nn.Module] = {}      # prefix -> module
@@ -78,6 +79,7 @@ class EngineHub:
         self.max_batch = max(self.max_batch, batch)
         cfg.max_batch = self.max_batch
         cfg.precision = N.PREC_BY_NAME[self.precision]
+        cfg.flags = N.CFG_FUSE_LN if self.fuse_ln else 0
         h = C.c_void_p()
         idx = device.index if device.index is not None else torch.cuda.current_device()
         N.check(N.lib().wm_create(C.byref(cfg), idx, C.byref(h)))
