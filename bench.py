@@ -170,7 +170,7 @@ def main() -> None:
             peak = PEAK_TFLOPS[a.precision if a.precision in PEAK_TFLOPS else "bf16"]
             traffic = None
             try:   # HBM bytes per GEMM launch from the PMC passes committed under profiles/ (collected offline with rocprofv3)
-                with open(os.path.join(ROOT, "profiles", "r1f_pmc_traffic.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r1g_pmc_traffic.json")) as f:
                     traffic = json.load(f)["classes"]["gemm16"]["hbm_bytes_per_launch"]
                 if a.model != "vit_h" or B != 4:
                     traffic = None          # the committed counters are for the default workload only
@@ -179,7 +179,7 @@ def main() -> None:
             roofline = {"bound": "mfma", "kernel": "gemm16v5_kernel<T,320|256,3> (all 16-bit MFMA GEMM launches)",
                         "achieved": round(achieved, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                        "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1f_pmc_traffic.json (B=4 run, tools/pmc_summarize.py)",
+                        "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1g_pmc_traffic.json (B=4 run, tools/pmc_summarize.py)",
                         "launches_per_step": g["launches"] // a.steps,
                         "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
                         "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
