@@ -567,19 +567,35 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
         }
         SoftmaxState<G::NDT> st;
         st.init();
+        // 196 keys = 3 tiles of 64 + 4: fewer, longer softmax steps (each step's max -> exchange -> exp -> convert chain is
+        // latency the 1.75 waves per SIMD cannot hide); the key loop stays fully unrolled so the bias is register selects
+        auto bias_of = [&](int key0, int key1) {         // rel-pos bias of this lane's element: key0 (half 0) / key1 (half 1)
+            const float b0 = key0 < NTOK ? U[(key0 < NTOK ? key0 : 0) / WS] + V[(key0 < NTOK ? key0 : 0) % WS] : 0.f;
+            const float b1 = key1 < NTOK ? U[(key1 < NTOK ? key1 : 0) / WS] + V[(key1 < NTOK ? key1 : 0) % WS] : 0.f;
+            return h ? b1 : b0;
+        };
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
+        for (int j = 0; j < 3; ++j) {
+            f32x16 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k0 = 64 * j + 32 * t + (r & 3) + 8 * (r >> 2);
+                    s[t][r] = bias_of(k0, k0 + 4);
+                }
+            qk_tile<T, HD, 2>(s, qf, sK + j * 64 * G::KS, lane);
+            softmax_pv<T, HD, 2>(st, s, c1, 0.f, 64, sV + j * 64 * G::VS, lane);
+        }
+        {
             f32x16 s[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // key index of this element for lane half 0 / 1: compile-time after unrolling
-                const int k0 = 32 * j + (r & 3) + 8 * (r >> 2), k1 = k0 + 4;
-                const float b0 = k0 < NTOK ? U[(k0 < NTOK ? k0 : 0) / WS] + V[(k0 < NTOK ? k0 : 0) % WS] : 0.f;
-                const float b1 = k1 < NTOK ? U[(k1 < NTOK ? k1 : 0) / WS] + V[(k1 < NTOK ? k1 : 0) % WS] : 0.f;
-                s[0][r] = h ? b1 : b0;
+                const int k0 = 192 + (r & 3) + 8 * (r >> 2);
+                s[0][r] = bias_of(k0, k0 + 4);
             }
-            qk_tile<T, HD, 1>(s, qf, sK + j * 32 * G::KS, lane);
-            softmax_pv<T, HD, 1>(st, s, c1, 0.f, NTOK - 32 * j, sV + j * 32 * G::VS, lane);
+            qk_tile<T, HD, 1>(s, qf, sK + 192 * G::KS, lane);
+            softmax_pv<T, HD, 1>(st, s, c1, 0.f, NTOK - 192, sV + 192 * G::VS, lane);
         }
         {
             int b, win, head;
