@@ -282,6 +282,30 @@ def test_cpu_tensor_fails_loudly():
         m(NestedTensor(torch.zeros(1, 3, 1024, 1024), None), None)
 
 
+def test_vit_l_vs_oracle():
+    """The registry's third entry (build_sam.py:30-41: 1024 wide, 24 blocks, global blocks 5/11/17/23; 256-column GEMM
+    tiles, 4-tile LayerNorm, hd 64 attention).  No reference fixture is committed for it, so the check is against the
+    CPU oracle (which the ViT-B / ViT-H fixtures pin) on one tile, bf16 mode, the same 1e-3 bar."""
+    m, post = _model("vit_l", "bf16")
+    x = torch.from_numpy(synth.make_batch(5, 1))
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = O.model_forward(x, sd, O.OracleCfg.from_model_type("vit_l"))
+    with torch.no_grad():
+        out = m.detect(x.to(G.dev()))
+    lerr = G.rel_l2(out["pred_logits"].cpu(), ref["pred_logits"])
+    berr = (out["pred_boxes"].cpu() - ref["pred_boxes"]).abs().max().item()
+    print(f"[vit_l/bf16] logits={lerr:.2e} boxes_maxabs={berr:.2e}")
+    assert lerr < LOGIT_TOL["bf16"], lerr
+    assert berr < 5 * LOGIT_TOL["bf16"], berr
+    det = O.detect(O.postprocess(ref["pred_logits"], ref["pred_boxes"], torch.tensor([[1024, 1024]]))[0])
+    rec = split_records(out["records"].cpu())
+    flags, rank = rec["flags"][0], rec["nms_rank"][0]
+    pos = torch.cumsum(((flags & 2) != 0).long(), 0) - 1
+    slots = torch.nonzero((flags & 4) != 0).flatten()
+    slots = slots[torch.argsort(rank[slots])]
+    assert pos[slots].tolist() == det["nms_index"].tolist()
+
+
 # ViT-H last: it replaces the resident ViT-B model
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
 def test_vit_h_vs_reference_golden(prec, golden_dir):
