@@ -5,10 +5,14 @@
 
 A "step" is one pass of the hot path over one batch of synthetic 1024x1024 tiles that is already
 resident in HBM: FFT high-pass -> ViT-H encoder -> detection decoder -> PostProcess + NMS
-(`--workload full`, the default), or the encoder alone (`--workload encoder` = BASELINE.json
-configs[1] literally).  Default batch is 4 tiles per GPU (configs[1]); `--batch 16` gives configs[2].
-With N > 1 tiles shard data-parallel, one process per GPU, and every step ends with the single
-fixed-size RCCL all-gather of box records (dist.py); per-GPU work is constant -> weak scaling.
+(`--workload full`, the default), or the encoder alone (`--workload encoder`).  Default batch is
+16 tiles per GPU = BASELINE.json configs[2], the largest single-GPU configuration (and configs[3]'s
+per-GPU share: 128 tiles over 8 GPUs); `--batch 4 --workload encoder` is configs[1] literally,
+`--precision fp8` configs[4].  With N > 1 tiles shard data-parallel, one process per GPU, and every
+step ends with the single fixed-size RCCL all-gather of box records (dist.py); per-GPU work is
+constant -> weak scaling.  `--gpus N` without a torch.distributed.run environment starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process (before this
+process touches the GPU) and exits with its return code.
 
 One JSON line on rank 0.  `roofline` is for the dominant kernel class (the 16-bit MFMA GEMM):
 algorithmic FLOPs of its launches / their summed duration, measured with HIP events on the
@@ -26,16 +30,49 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+
+def _self_launch_if_needed() -> None:
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as a CHILD process group
+    (never exec: this process may not replace itself once a GPU runtime is loaded) and leave with the child's code."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    n = 1
+    for i, tok in enumerate(sys.argv):
+        if tok == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif tok.startswith("--gpus="):
+            n = int(tok.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rc = subprocess.call(cmd, env=env)
+    sys.exit(rc if rc >= 0 else 1)
+
+
+if __name__ == "__main__":
+    _self_launch_if_needed()          # before torch / HIP are imported
+
 import torch
 import torch.distributed as dist
 
+from wildlifemapper_amd import _native as N_
 from wildlifemapper_amd import dist as wdist
 from wildlifemapper_amd import synth
 
 # SURVEY.md §8d: algorithmic FLOPs per tile (useful work only)
 FLOPS_FULL = {"vit_h": 5797.8e9, "vit_b": 1115.96e9 + 3.55e9}
 FLOPS_ENC = {"vit_h": 5794.3e9, "vit_b": 1115.96e9}
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0}      # MI355X dense MFMA peak (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp8": 5000.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 
 
 def build_model(model_type: str, precision: str, device: torch.device):
@@ -49,14 +86,17 @@ def build_model(model_type: str, precision: str, device: torch.device):
     return model, sd
 
 
-def cpu_baseline(model_type: str, sd, model, device) -> tuple:
+def cpu_baseline(model_type: str, sd, model, device, x_batch, ts_batch, first_tile: int) -> tuple:
     """Oracle (CPU port of the reference, fp32) on one tile, timed; and the BASELINE metric's second half,
-    "mAP vs CPU ref": the GPU path's detections on the same tile scored against the CPU detections as ground truth
-    (own COCO-style evaluator, wildlifemapper_amd/coco_eval.py).  Checker code, used here only as a baseline."""
+    "mAP vs CPU ref": the GPU path's detections scored against the CPU detections as ground truth (own COCO-style
+    evaluator, wildlifemapper_amd/coco_eval.py).  The tile checked is tile 0 OF THE TIMED BATCH, taken from one more
+    pass over that same resident batch (same batch size, hence the same kernel instances as the timed steps).
+    Checker code, used here only as a baseline."""
     from oracle import wm_oracle as O
     from wildlifemapper_amd.coco_eval import map_vs_reference
     from wildlifemapper_amd.engine import split_records
-    x = torch.from_numpy(synth.make_batch(0, 1))
+    x = torch.from_numpy(synth.make_batch(first_tile, 1))
+    assert torch.equal(x[0], x_batch[0].cpu()), "timed batch does not start with the checked tile"
     cfg = O.OracleCfg.from_model_type(model_type)
     threads = torch.get_num_threads()
     t0 = time.time()
@@ -67,7 +107,8 @@ def cpu_baseline(model_type: str, sd, model, device) -> tuple:
     ts = torch.tensor([[1024, 1024]])
     det_ref = O.detect(O.postprocess(ref["pred_logits"], ref["pred_boxes"], ts)[0])
     with torch.no_grad():
-        out = model.detect(x.to(device), ts.float().to(device))
+        out = model.detect(x_batch, ts_batch)
+    out = {k: v[:1] for k, v in out.items()}
     rec = split_records(out["records"].cpu())
     kept = (rec["flags"][0] & 4) != 0
     order = torch.argsort(rec["nms_rank"][0][kept])
@@ -76,11 +117,25 @@ def cpu_baseline(model_type: str, sd, model, device) -> tuple:
     gt = {0: {"boxes": det_ref["boxes"].numpy(), "scores": det_ref["scores"].numpy(), "labels": det_ref["labels"].numpy()}}
     m = map_vs_reference(pred, gt)
     lg = out["pred_logits"].cpu()
-    parity = {"mAP": round(m["mAP"], 4), "mAP50": round(m["mAP50"], 4), "tiles": 1,
+    parity = {"mAP": round(m["mAP"], 4), "mAP50": round(m["mAP50"], 4), "tiles": 1, "tile": f"tile 0 of the timed batch of {x_batch.shape[0]}",
               "detections_gpu": int(kept.sum()), "detections_cpu": int(len(det_ref["scores"])),
               "logits_rel_l2": float(((lg - ref["pred_logits"]).norm() / ref["pred_logits"].norm()).item()),
               "evaluator": "own COCO-style bbox AP@[.5:.95], CPU-reference detections as ground truth"}
     return base, parity
+
+
+def _config_name(a, B: int, world: int) -> str:
+    """Which BASELINE.json config this run is, derived from what actually runs."""
+    if a.model != "vit_h":
+        return "not a BASELINE.json config"
+    if a.precision == "fp8":
+        return "BASELINE.json configs[4]" if (B == 16 and world == 1 and a.workload == "full") else "fp8 variant, not the configs[4] batch"
+    if a.workload == "encoder":
+        return "BASELINE.json configs[1]" if (B == 4 and world == 1) else "encoder only, not the configs[1] batch"
+    if B == 16:
+        return "BASELINE.json configs[2]" if world == 1 else (f"BASELINE.json configs[3]: {16 * world} tiles over {world} GPUs" if world == 8
+                                                               else f"configs[2] per GPU, {world} GPUs")
+    return "full path, not a BASELINE.json batch"
 
 
 def main() -> None:
@@ -88,7 +143,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="tiles per GPU per step")
+    ap.add_argument("--batch", type=int, default=16, help="tiles per GPU per step (16 = BASELINE.json configs[2])")
     ap.add_argument("--model", default="vit_h")
     ap.add_argument("--precision", default=os.environ.get("WM_PRECISION", "bf16"))
     ap.add_argument("--workload", default="full", choices=["full", "encoder"])
@@ -102,9 +157,7 @@ def main() -> None:
     if a.same_device:
         local = 0
     if world != a.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        a.gpus = world
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
@@ -155,6 +208,7 @@ def main() -> None:
         if rank == 0:
             hub.profile_enable(True)
             hub.profile_reset()
+            N_.gemm_variant_counts(reset=True)
         with torch.no_grad():
             sync()
             t1 = time.perf_counter()
@@ -165,28 +219,35 @@ def main() -> None:
         if rank == 0:
             st = hub.profile_read()
             hub.profile_enable(False)
+            gemm_instances = {k: v // a.steps for k, v in N_.gemm_variant_counts().items() if v}
             g = st["gemm16"]
             achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
             peak = PEAK_TFLOPS[a.precision if a.precision in PEAK_TFLOPS else "bf16"]
             traffic = None
+            traffic_src = None
             try:   # HBM bytes per GEMM launch from the PMC passes committed under profiles/ (collected offline with rocprofv3)
-                with open(os.path.join(ROOT, "profiles", "r1g_pmc_traffic.json")) as f:
-                    traffic = json.load(f)["classes"]["gemm16"]["hbm_bytes_per_launch"]
-                if a.model != "vit_h" or B != 4:
-                    traffic = None          # the committed counters are for the default workload only
+                for name in ("r2_pmc_traffic.json", "r1g_pmc_traffic.json"):
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        t = json.load(f)
+                    # the committed counters belong to one workload: use them only for that one
+                    if a.model == "vit_h" and a.workload == "full" and int(t.get("batch", 4)) == B and t.get("precision", "bf16") == a.precision:
+                        traffic = t["classes"]["gemm16"]["hbm_bytes_per_launch"]
+                        traffic_src = name
+                        break
             except Exception:
                 traffic = None
             roofline = {"bound": "mfma", "kernel": "gemm16v5_kernel<T,320|256,3> (all 16-bit MFMA GEMM launches)",
                         "achieved": round(achieved, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                        "traffic_note": "HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1g_pmc_traffic.json (B=4 run, tools/pmc_summarize.py)",
+                        "traffic_note": f"HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/{traffic_src} (tools/pmc_summarize.py)" if traffic_src else None,
                         "launches_per_step": g["launches"] // a.steps,
                         "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
                         "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
                         "ms_per_step_with_events": round(prof_elapsed / a.steps * 1e3, 3),
                         "sustained_clock_note": "power-limited: in-kernel s_memtime / wall clock (WM_GEMM_DBG=1) reads ~1.5 GHz at the "
                                                 "31st GEMM of a step (1.79 GHz isolated, 1.34 GHz in a GEMM-only loop), i.e. ~1.57 "
-                                                "PFLOP/s of dense bf16 MFMA at the sustained clock; DESIGN.md section 5"}
+                                                "PFLOP/s of dense bf16 MFMA at the sustained clock; DESIGN.md section 5",
+                        "gemm_instances_per_step": gemm_instances}
             classes = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["launches"] // a.steps,
                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
                        for k, v in st.items()}
@@ -200,8 +261,7 @@ def main() -> None:
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": (f"{a.model} {'encoder only' if a.workload == 'encoder' else 'full path fft+encoder+decoder+PostProcess/NMS'}"
-                                    f", {a.precision} MFMA, batch={B} tiles/GPU of 1024x1024x3 (BASELINE.json configs[1] batch"
-                                    f"{'' if a.workload == 'encoder' else ', configs[2]/[3] scope'})"),
+                                    f", {a.precision} MFMA, batch={B} tiles/GPU of 1024x1024x3 ({_config_name(a, B, world)})"),
                        "tiles_per_step": n_tiles, "parallelism": f"dp{world} tile shard" + (f", {'RCCL' if a.backend == 'nccl' else a.backend} all-gather of box records" if world > 1 and a.workload == "full" else ""),
                        "weights": "seed 0 synthetic (random init)"},
             "model_tflops": round(tiles_per_s * flops_tile / 1e12, 1) if flops_tile else None,
@@ -209,7 +269,7 @@ def main() -> None:
             "roofline": roofline, "kernel_classes": classes,
         }
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"], line["map_vs_cpu_ref"] = cpu_baseline(a.model, sd, model, device)
+            line["cpu_baseline"], line["map_vs_cpu_ref"] = cpu_baseline(a.model, sd, model, device, x, ts, first)
         else:
             line["cpu_baseline"], line["map_vs_cpu_ref"] = None, None
         print(json.dumps(line), flush=True)

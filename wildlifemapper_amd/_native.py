@@ -15,6 +15,8 @@ PREC_BF16, PREC_FP16 = 0, 1
 PREC_BY_NAME = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16}
 NUM_QUERIES, NUM_LOGITS = 51, 8
 KCLASS_NAMES = ("gemm16", "attn_window", "attn_global", "layernorm", "other")
+GEMM_VARIANTS = ("v1_128", "v2_160", "v2_128", "v3_lockstep", "v3_conv3x3", "v5_320", "v5_320_res", "v5_256", "v5_256_res",
+                 "v5_320_lnf", "v5_256_lnf", "fp8_320", "fp8_256")
 FLAG_CONF, FLAG_SCORE, FLAG_NMS = 1, 2, 4
 CFG_FUSE_LN = 1
 
@@ -54,6 +56,8 @@ SYMBOLS = {
     "wm_profile_enable": (_I, [_P, _I]),
     "wm_profile_reset": (_I, [_P]),
     "wm_profile_read": (_I, [_P, C.POINTER(WmKclassStat)]),
+    "wm_debug_gemm_variant_counts": (_I, [C.POINTER(_L), _I]),
+    "wm_debug_reset_gemm_variant_counts": (_I, []),
     "wm_op_cvt_f32_to_16": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_cvt_16_to_f32": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_gemm16": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -86,6 +90,15 @@ def lib() -> C.CDLL:
             raise RuntimeError("libwm_hip.so ABI version mismatch")
         _lib = l
     return _lib
+
+
+def gemm_variant_counts(reset: bool = False) -> dict:
+    """{variant name: launches since the last reset} (wm_debug_gemm_variant_counts)."""
+    arr = (C.c_int64 * len(GEMM_VARIANTS))()
+    check(lib().wm_debug_gemm_variant_counts(arr, len(GEMM_VARIANTS)))
+    if reset:
+        lib().wm_debug_reset_gemm_variant_counts()
+    return {n: int(arr[i]) for i, n in enumerate(GEMM_VARIANTS)}
 
 
 def check(status: int) -> None:

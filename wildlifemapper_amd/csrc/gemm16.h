@@ -161,8 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Args p) {
                 v += b;
             }
             if (p.act == ACT_GELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
+                v = gelu_erf_fast4(v);      // the same arithmetic in every GEMM kernel: a tile's bits must not depend on which one its batch size selects
             } else if (p.act == ACT_RELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);

@@ -184,8 +184,7 @@ template <class T, int BN> struct G2Core {
     static __device__ __forceinline__ f32x4 finish(const Gemm16Args& p, f32x4 v, int m, int n, int res_mod) {
         if (p.bias) v += *(const f32x4*)(p.bias + n);
         if (p.act == ACT_GELU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
+            v = gelu_erf_fast4(v);      // the same arithmetic in every GEMM kernel: a tile's bits must not depend on which one its batch size selects
         } else if (p.act == ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);

@@ -29,6 +29,10 @@
 
 #include "gemm16.h"
 
+#ifndef WM_GEMM_TIMING_BITS
+#define WM_GEMM_TIMING_BITS 0
+#endif
+
 namespace wm {
 
 template <int BN, int WN> struct G3 {
@@ -70,7 +74,8 @@ __global__ __launch_bounds__((G3<BN, WN>::THREADS), 2) void gemm16v3_kernel(Gemm
     const char* Ab = (const char*)p.A;
     const char* Wb = (const char*)p.W;
     const bool extra = wave < C::W_REM;                              // this wave issues W_LO + 1 W pieces
-    const bool dbg_nostore = (p.act & 0x100) != 0, dbg_nodma = (p.act & 0x200) != 0;   // timing experiments (tools/gemm_bench.py)
+    constexpr bool TB = WM_GEMM_TIMING_BITS != 0;                        // timing experiments (tools/gemm_bench.py), off in the product
+    const bool dbg_nostore = TB && (p.act & 0x100) != 0, dbg_nodma = TB && (p.act & 0x200) != 0;
     const int act = p.act & 0xff;
 
     // grouped tile order + XCD remap (as gemm16_v2.h)
@@ -206,8 +211,7 @@ __global__ __launch_bounds__((G3<BN, WN>::THREADS), 2) void gemm16v3_kernel(Gemm
             f32x4 v = acc[mi][ni];
             if (p.bias) v += *(const f32x4*)(p.bias + n);
             if (act == ACT_GELU) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
+                v = gelu_erf_fast4(v);      // the same arithmetic in every GEMM kernel: a tile's bits must not depend on which one its batch size selects
             } else if (act == ACT_RELU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);

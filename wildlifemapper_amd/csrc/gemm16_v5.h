@@ -24,6 +24,10 @@
 #pragma once
 #include "gemm16_v3.h"
 
+#ifndef WM_GEMM_TIMING_BITS
+#define WM_GEMM_TIMING_BITS 0
+#endif
+
 namespace wm {
 
 // DBG (dev only, WM_GEMM_DBG=1, see launch_gemm16v5_t): waves 0 and 4 of workgroup 0 record s_memtime at six marks of
@@ -34,7 +38,9 @@ template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     using C = G3<BN, 4>;
     constexpr int AHEAD = NSLOT - 1;                       // K-steps of DMA in flight
-    const bool dbg_nostore = (p.act & 0x100) != 0, dbg_nodma = (p.act & 0x200) != 0, dbg_noissue = (p.act & 0x400) != 0;
+    // timing experiments of tools/gemm_bench.py (--act 256 / 512 / 1024): compiled in only with -DWM_GEMM_TIMING_BITS=1
+    constexpr bool TB = WM_GEMM_TIMING_BITS != 0;
+    const bool dbg_nostore = TB && (p.act & 0x100) != 0, dbg_nodma = TB && (p.act & 0x200) != 0, dbg_noissue = TB && (p.act & 0x400) != 0;
     static_assert(C::W_REM == 0 || C::W_REM == 4, "remainder pieces must fall on one wave group");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long wt0 = 0, wt1 = 0, wt2 = 0, mt1 = 0, mt2 = 0, we[6] = {0, 0, 0, 0, 0, 0};

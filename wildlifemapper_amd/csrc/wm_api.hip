@@ -7,7 +7,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <algorithm>
 #include <vector>
@@ -53,6 +56,69 @@ static int fail(const char* fmt, ...) {
 
 extern "C" const char* wm_last_error(void) { return g_err; }
 extern "C" int wm_abi_version(void) { return WM_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------
+// per-device launcher state (a process may drive several devices, one handle each)
+// ---------------------------------------------------------------------------
+static std::mutex g_dev_mu;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per (function, device)
+static int set_max_lds(const void* fn, int bytes) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    static std::set<std::pair<const void*, int>> done;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (done.count({fn, dev})) return 0;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({fn, dev});
+    return 0;
+}
+
+static int num_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    static std::map<int, int> cus;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    hipDeviceProp_t prop;
+    int n = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    cus[dev] = n;
+    return n;
+}
+
+// 256 B of zeros per device: source of out-of-image taps of the implicit-GEMM conv
+static int zero_page_for_device(const uint16_t** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    static std::map<int, uint16_t*> pages;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = pages.find(dev);
+    if (it == pages.end()) {
+        uint16_t* p = nullptr;
+        HIP_TRY(hipMalloc((void**)&p, 256));
+        HIP_TRY(hipMemset(p, 0, 256));
+        it = pages.emplace(dev, p).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+// which GEMM kernel instance each launch took (wm_debug_gemm_variant_counts): the tests assert on it, so that a
+// change of the dispatch heuristic cannot silently leave an instance without a value check
+static std::atomic<int64_t> g_variant_count[WM_GEMM_VARIANT_COUNT];
+static inline void count_variant(int v) { g_variant_count[v].fetch_add(1, std::memory_order_relaxed); }
+
+extern "C" int wm_debug_gemm_variant_counts(int64_t* out, int n) {
+    if (!out || n < WM_GEMM_VARIANT_COUNT) return fail("wm_debug_gemm_variant_counts: need room for %d counters", WM_GEMM_VARIANT_COUNT);
+    for (int i = 0; i < WM_GEMM_VARIANT_COUNT; ++i) out[i] = g_variant_count[i].load(std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int wm_debug_reset_gemm_variant_counts(void) {
+    for (auto& c : g_variant_count) c.store(0, std::memory_order_relaxed);
+    return 0;
+}
 
 // ---------------------------------------------------------------------------
 // host-side 16-bit conversion (round to nearest even), used by the weight packer
@@ -118,7 +184,7 @@ struct LnFuseState {
 struct wm_handle {
     wm_config cfg{};
     LnFuseState lnf;
-    int fp16_tail = 0;      // bf16 mode: the last fp16_tail transformer blocks use fp16 operands (parity margin)
+    int fp16_tail = 0;      // bf16 mode: the last fp16_tail transformer blocks use fp16 operands (parity margin; default depth / 4)
     int device = 0;
     int D = 0, depth = 0, heads = 0, hd = 0, prec = 0, maxB = 0;
     bool is_global[64] = {};
@@ -200,11 +266,8 @@ int prof_collect(wm_handle* h) {
 // -------- launchers --------
 template <class T16>
 int launch_gemm16_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm16_kernel<T16>, hipFuncAttributeMaxDynamicSharedMemorySize, G16_LDS_BYTES));
-        attr_set = true;
-    }
+    WM_TRY(set_max_lds((const void*)gemm16_kernel<T16>, G16_LDS_BYTES));
+    count_variant(WM_GEMM_V1_128);
     const int grid = (a.M / G16_BM) * (a.N / G16_BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
@@ -215,11 +278,8 @@ int launch_gemm16_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
 
 template <class T16, int BN>
 int launch_gemm16v2_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v2_kernel<T16, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, G2<BN>::LDS));
-        attr_set = true;
-    }
+    WM_TRY(set_max_lds((const void*)gemm16v2_kernel<T16, BN>, G2<BN>::LDS));
+    count_variant(BN == 160 ? WM_GEMM_V2_160 : WM_GEMM_V2_128);
     const int grid = (a.M / 256) * (a.N / BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
@@ -231,11 +291,8 @@ int launch_gemm16v2_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
 template <class T16, int BN, int WN>
 int launch_gemm16v3_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     using G = G3<BN, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v3_kernel<T16, BN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        attr_set = true;
-    }
+    WM_TRY(set_max_lds((const void*)gemm16v3_kernel<T16, BN, WN>, G::LDS));
+    count_variant(WM_GEMM_V3_LOCKSTEP);
     const int grid = (a.M / 256) * (a.N / BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
@@ -249,11 +306,8 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     using G = G3<BN, 4>;
     constexpr int LDS = NSLOT * G::STAGE + 32 * BN * 4;        // ring + the first residual landing buffer
     static_assert(LDS <= 160 * 1024, "LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v5_kernel<T16, BN, NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, NSLOT>, LDS));
+    count_variant(BN == 320 ? (a.residual ? WM_GEMM_V5_320_RES : WM_GEMM_V5_320) : (a.residual ? WM_GEMM_V5_256_RES : WM_GEMM_V5_256));
     const int grid = (a.M / 256) * (a.N / BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
@@ -269,8 +323,7 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
             HIP_TRY(hipMemsetAsync(buf, 0, bytes, s));
             Gemm16Args d = a;
             d.zero_page = (const u16*)buf;
-            static bool set2 = false;
-            if (!set2) { HIP_TRY(hipFuncSetAttribute((const void*)gemm16v5_kernel<T16, BN, NSLOT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); set2 = true; }
+            WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, NSLOT, true>, LDS));
             hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, NSLOT, true>), dim3(grid), dim3(512), LDS, s, d);
             HIP_TRY(hipStreamSynchronize(s));
             std::vector<unsigned char> hbuf(bytes);
@@ -324,17 +377,6 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
 // ---- fused residual GEMM + LayerNorm (gemm16_v5.h, LNF instance) ----
 static LnFuseState g_lnf;
 
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return n;
-}
-
 // Which column tile the fused kernel would use, or 0 if this shape must keep the separate LayerNorm kernel: every
 // workgroup of a row block has to be resident together, i.e. the grid fits the chip, or the XCD remap hands each XCD
 // whole groups of 8 row blocks (then a round never splits a row block).
@@ -354,11 +396,8 @@ template <class T16, int BN>
 int launch_gemm16v5_ln_t(wm_handle* h, hipStream_t s, Gemm16Args a) {
     using G = G3<BN, 4>;
     constexpr int LDS = 3 * G::STAGE + 32 * BN * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v5_kernel<T16, BN, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, true>, LDS));
+    count_variant(BN == 320 ? WM_GEMM_V5_320_LNF : WM_GEMM_V5_256_LNF);
     LnFuseState& g_lnf = h ? h->lnf : ::g_lnf;
     const int mtiles = a.M / 256, tn = a.N / BN;
     const size_t need = (size_t)a.M * tn * 2;
@@ -498,19 +537,13 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
 // out[M = B*4096, N] = conv(A) with W packed [N][tap][C]  (image_encoder.py:113-119)
 int launch_conv3x3_16(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, float* out32, int M, int N, int Cin) {
     if (M % 4096 || N % 256 || Cin % 32) return fail("conv3x3: M=%d N=%d C=%d unsupported (M %% 4096, N %% 256, C %% 32)", M, N, Cin);
-    static uint16_t* zero_page = nullptr;      // 256 B of zeros for out-of-image taps (one per process)
-    if (!zero_page) {
-        HIP_TRY(hipMalloc((void**)&zero_page, 256));
-        HIP_TRY(hipMemset(zero_page, 0, 256));
-    }
+    const uint16_t* zero_page = nullptr;       // 256 B of zeros for out-of-image taps (one per device)
+    WM_TRY(zero_page_for_device(&zero_page));
     Gemm16Args a{(const u16*)A, (const u16*)W, nullptr, nullptr, out32, nullptr, M, N, 9 * Cin, 0, ACT_NONE, Cin, (const u16*)zero_page};
     using G = G3<256, 4>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v3_kernel<FP16, 256, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm16v3_kernel<BF16, 256, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        attr_set = true;
-    }
+    WM_TRY(set_max_lds((const void*)gemm16v3_kernel<FP16, 256, 4, 1>, G::LDS));
+    WM_TRY(set_max_lds((const void*)gemm16v3_kernel<BF16, 256, 4, 1>, G::LDS));
+    count_variant(WM_GEMM_V3_CONV3X3);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * M * (double)N * 9 * Cin, 2.0 * ((double)M * Cin + 9.0 * N * Cin) + 4.0 * M * N);
     if (prec == WM_PREC_FP16) hipLaunchKernelGGL((gemm16v3_kernel<FP16, 256, 4, 1>), dim3((M / 256) * (N / 256)), dim3(G::THREADS), G::LDS, s, a);
     else hipLaunchKernelGGL((gemm16v3_kernel<BF16, 256, 4, 1>), dim3((M / 256) * (N / 256)), dim3(G::THREADS), G::LDS, s, a);
@@ -571,11 +604,7 @@ int launch_layernorm_block(wm_handle* h, hipStream_t s, int prec, const float* x
 template <class T16, int HD, bool REL>
 int launch_attn_global_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int batch, int kclass) {
     using L = GlobalLds<HD, REL>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)attn_global_kernel<T16, HD, REL>, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL));
-        attr_set = true;
-    }
+    WM_TRY(set_max_lds((const void*)attn_global_kernel<T16, HD, REL>, L::TOTAL));
     Bracket br(h, s, kclass, 4.0 * batch * a.heads * (double)a.nq * a.nk * HD, 0.0);
     hipLaunchKernelGGL((attn_global_kernel<T16, HD, REL>), dim3(a.nq / 128, a.heads, batch), dim3(256), L::TOTAL, s, a);
     HIP_TRY(hipGetLastError());
@@ -597,20 +626,9 @@ int launch_attn_global_p(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
 template <class T16, int HD>
 int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int batch) {
     using L = WindowLds<HD>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)attn_window_kernel<T16, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, L::TOTAL));
-        attr_set = true;
-    }
+    WM_TRY(set_max_lds((const void*)attn_window_kernel<T16, HD>, L::TOTAL));
     // useful work only: 4096 real queries x 196 keys
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int num_cu = num_cus();
     const int nitems = 25 * a.heads * batch;
     const int grid = nitems < num_cu ? nitems : num_cu;
     Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);
@@ -834,7 +852,9 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     HIP_TRY(hipSetDevice(device));
     wm_handle* h = new wm_handle();
     h->cfg = *cfg; h->device = device;
-    h->fp16_tail = getenv("WM_FP16_TAIL") ? atoi(getenv("WM_FP16_TAIL")) : 0;
+    // bf16 mode: the last depth/4 blocks use fp16 operands (nothing after them averages their rounding error out): logits
+    // margin against the 1e-3 bar 8.3e-4 -> 6.6e-4 (ViT-H), 9.2e-4 -> 7.4e-4 (ViT-L) for ~1 % of throughput; WM_FP16_TAIL=K overrides
+    h->fp16_tail = getenv("WM_FP16_TAIL") ? atoi(getenv("WM_FP16_TAIL")) : cfg->depth / 4;
     h->D = cfg->embed_dim; h->depth = cfg->depth; h->heads = cfg->num_heads; h->hd = hd;
     h->prec = cfg->precision; h->maxB = cfg->max_batch;
     for (int i = 0; i < cfg->num_global; ++i) {
@@ -1010,14 +1030,14 @@ int check_ready(wm_handle* h, int batch, const char* fn, bool need_enc, bool nee
 const uint16_t* W16(wm_handle* h, const std::string& n) { return h->w16.at(n); }
 const float* W32(wm_handle* h, const std::string& n) { return h->w32.at(n); }
 
-int do_tap(wm_handle* h, hipStream_t s, int which, int batch) {
+int do_tap(wm_handle* h, hipStream_t s, int which, int batch, const float* src = nullptr) {
     if (h->tap_which != which) return 0;
     if (!h->tap_buf) {
         void* p = nullptr;
         HIP_TRY(hipMalloc(&p, (size_t)h->maxB * T * h->D * 4));
         h->tap_buf = (float*)p;
     }
-    HIP_TRY(hipMemcpyAsync(h->tap_buf, h->resid, (size_t)batch * T * h->D * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->tap_buf, src ? src : h->resid, (size_t)batch * T * h->D * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
@@ -1039,6 +1059,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     // t = patch_embed(x) + pos_embed  -> tokbase (fp32) and xn16 (16-bit copy for proj_patch)
     WM_TRY(launch_gemm16(h, s, PS, h->p16, W16(h, e + "patch_embed.proj.weight"), W32(h, e + "patch_embed.proj.bias"),
                          W32(h, e + "pos_embed"), T, h->tokbase, h->xn16, M, D, 768, ACT_NONE));
+    WM_TRY(do_tap(h, s, -3, B, h->tokbase));
     WM_TRY(launch_gemm16(h, s, PS, h->h16, W16(h, e + "hfc_embed.proj.weight"), W32(h, e + "hfc_embed.proj.bias"),
                          nullptr, 0, nullptr, h->he16, M, HFC, 256, ACT_NONE));
     // ---- HFC adaptor (image_encoder.py:486-516) ----
@@ -1236,7 +1257,11 @@ extern "C" int wm_hfc_fft(wm_handle* h, const float* x_dev, float* hfc_dev, int 
 extern "C" int wm_encoder_forward(wm_handle* h, const float* x_dev, const float* hfc_dev, float* out_dev, int batch, void* stream) {
     WM_TRY(check_ready(h, batch, "wm_encoder_forward", true, false));
     if (!x_dev || !hfc_dev || !out_dev) return fail("wm_encoder_forward: null buffer");
-    return encoder_impl(h, x_dev, hfc_dev, out_dev, batch, (hipStream_t)stream);
+    WM_TRY(encoder_impl(h, x_dev, hfc_dev, out_dev, batch, (hipStream_t)stream));
+    // opt-in fused GEMM + LayerNorm: a partner time-out means wrong numbers, so it must never pass silently; the check
+    // reads the flag on the launch stream (one stream synchronisation per call, paid only with the option on)
+    if (h->cfg.flags & WM_CFG_FUSE_LN) WM_TRY(ln_fuse_check(h, (hipStream_t)stream));
+    return 0;
 }
 
 extern "C" int wm_decoder_forward(wm_handle* h, const float* emb_dev, float* logits_dev, float* boxes_dev, int batch, void* stream) {
@@ -1250,10 +1275,9 @@ extern "C" int wm_decoder_forward(wm_handle* h, const float* emb_dev, float* log
 
 extern "C" int wm_postprocess_nms(wm_handle* h, const float* logits_dev, const float* boxes_dev, const float* target_sizes_dev,
                                   float conf_thr, float score_thr, float iou_thr, wm_box_record* records_dev, int batch, void* stream) {
-    if (!h) return fail("wm_postprocess_nms: null handle");
     if (batch <= 0) return fail("wm_postprocess_nms: batch %d", batch);
     if (!logits_dev || !boxes_dev || !target_sizes_dev || !records_dev) return fail("wm_postprocess_nms: null buffer");
-    HIP_TRY(hipSetDevice(h->device));
+    if (h) HIP_TRY(hipSetDevice(h->device));     // weightless kernel: a NULL handle launches on the current device
     return launch_simple(h, (hipStream_t)stream, 0.0, postprocess_nms_kernel, dim3(batch), dim3(64), logits_dev, boxes_dev,
                          target_sizes_dev, conf_thr, score_thr, iou_thr, records_dev);
 }
@@ -1272,6 +1296,7 @@ extern "C" int wm_forward(wm_handle* h, const float* x_dev, const float* target_
     if (logits_dev) HIP_TRY(hipMemcpyAsync(logits_dev, h->logits, (size_t)batch * NQ * WM_NUM_LOGITS * 4, hipMemcpyDeviceToDevice, s));
     if (boxes_dev) HIP_TRY(hipMemcpyAsync(boxes_dev, h->boxes, (size_t)batch * NQ * 16, hipMemcpyDeviceToDevice, s));
     if (records_dev) HIP_TRY(hipMemcpyAsync(records_dev, h->records, (size_t)batch * NQ * sizeof(wm_box_record), hipMemcpyDeviceToDevice, s));
+    if (h->cfg.flags & WM_CFG_FUSE_LN) WM_TRY(ln_fuse_check(h, s));     // see wm_encoder_forward
     return 0;
 }
 
@@ -1280,7 +1305,7 @@ extern "C" int wm_forward(wm_handle* h, const float* x_dev, const float* target_
 // ---------------------------------------------------------------------------
 extern "C" int wm_set_tap(wm_handle* h, int which) {
     if (!h) return fail("wm_set_tap: null handle");
-    if (which < -2 || which >= h->depth) return fail("wm_set_tap: %d out of range", which);
+    if (which < -3 || which >= h->depth) return fail("wm_set_tap: %d out of range", which);
     h->tap_which = which;
     return 0;
 }
@@ -1310,7 +1335,7 @@ extern "C" int wm_profile_read(wm_handle* h, wm_kclass_stat* out) {
     if (!h || !out) return fail("wm_profile_read: null argument");
     WM_TRY(prof_collect(h));
     for (int i = 0; i < WM_KCLASS_COUNT; ++i) out[i] = h->prof.acc[i];
-    return ln_fuse_check(h, nullptr);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -164,20 +164,6 @@ class EngineHub:
             out["records"] = rec
         return out
 
-    def postprocess_nms(self, logits: torch.Tensor, boxes: torch.Tensor, target_sizes: torch.Tensor,
-                        conf_thr: float = 0.05, score_thr: float = 0.5, iou_thr: float = 0.4) -> torch.Tensor:
-        """Returns raw records (B,51,8) float32-viewed: x0,y0,x1,y1,score | int32 label,flags,nms_rank."""
-        N.require_cuda(logits, "pred_logits")
-        N.require_cuda(boxes, "pred_boxes")
-        B = logits.shape[0]
-        if self._handle is None or self._device != logits.device:
-            self._create(logits.device, max(B, 1))
-        ts = target_sizes.to(device=logits.device, dtype=torch.float32).contiguous()
-        rec = torch.empty((B, N.NUM_QUERIES, 8), device=logits.device, dtype=torch.float32)
-        N.check(N.lib().wm_postprocess_nms(self._handle, N.ptr(logits), N.ptr(boxes), N.ptr(ts), conf_thr, score_thr, iou_thr,
-                                           N.ptr(rec), B, N.stream_ptr(logits.device)))
-        return rec
-
     # -- taps / profiling ---------------------------------------------------
     def set_tap(self, which: int) -> None:
         N.check(N.lib().wm_set_tap(self._handle, which))
@@ -198,6 +184,23 @@ class EngineHub:
         N.check(N.lib().wm_profile_read(self._handle, arr))
         return {n: {"launches": int(arr[i].launches), "ms": float(arr[i].ms), "flops": float(arr[i].flops),
                     "bytes": float(arr[i].bytes)} for i, n in enumerate(N.KCLASS_NAMES)}
+
+
+def postprocess_nms(logits: torch.Tensor, boxes: torch.Tensor, target_sizes: torch.Tensor,
+                    conf_thr: float = 0.05, score_thr: float = 0.5, iou_thr: float = 0.4) -> torch.Tensor:
+    """PostProcess + score cut + NMS kernel (wm_postprocess_nms).  Weightless: no handle, no workspace.
+    Returns raw records (B,51,8) float32-viewed: x0,y0,x1,y1,score | int32 label,flags,nms_rank."""
+    N.require_cuda(logits, "pred_logits")
+    N.require_cuda(boxes, "pred_boxes")
+    B = logits.shape[0]
+    if tuple(logits.shape[1:]) != (N.NUM_QUERIES, N.NUM_LOGITS) or tuple(boxes.shape) != (B, N.NUM_QUERIES, 4):
+        raise RuntimeError(f"postprocess: expected (B,51,8) logits and (B,51,4) boxes, got {tuple(logits.shape)}, {tuple(boxes.shape)}")
+    ts = target_sizes.to(device=logits.device, dtype=torch.float32).contiguous()
+    rec = torch.empty((B, N.NUM_QUERIES, 8), device=logits.device, dtype=torch.float32)
+    with torch.cuda.device(logits.device):
+        N.check(N.lib().wm_postprocess_nms(None, N.ptr(logits), N.ptr(boxes), N.ptr(ts), conf_thr, score_thr, iou_thr,
+                                           N.ptr(rec), B, N.stream_ptr(logits.device)))
+    return rec
 
 
 def _check_image(x: torch.Tensor, chans: int) -> None:

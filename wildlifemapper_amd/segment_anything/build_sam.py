@@ -14,7 +14,7 @@ from typing import Dict, List, Optional
 import torch
 from torch import nn
 
-from ..engine import EngineHub, split_records
+from ..engine import postprocess_nms, split_records
 from .. import _native as N
 from .modeling import ImageEncoderViT, MaskDecoder, PromptEncoder, Sam, TwoWayTransformer
 
@@ -67,14 +67,13 @@ class PostProcess(nn.Module):
     def __init__(self, confidence_threshold: float = 0.05) -> None:
         super().__init__()
         self.confidence_threshold = confidence_threshold
-        self._hub = EngineHub(768, 12, 12, (2, 5, 8, 11))   # kernel needs no weights; hub only owns a handle
 
     def _records(self, outputs, target_sizes, score_thr, iou_thr):
         out_logits, out_bbox = outputs["pred_logits"], outputs["pred_boxes"]
         assert len(out_logits) == len(target_sizes)
         assert target_sizes.shape[1] == 2
-        rec = self._hub.postprocess_nms(out_logits.contiguous().float(), out_bbox.contiguous().float(), target_sizes,
-                                        self.confidence_threshold, score_thr, iou_thr)
+        rec = postprocess_nms(out_logits.contiguous().float(), out_bbox.contiguous().float(), target_sizes,
+                              self.confidence_threshold, score_thr, iou_thr)
         return split_records(rec)
 
     @torch.no_grad()
