@@ -153,6 +153,8 @@ def main() -> None:
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     a = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (no CPU fallback)")
     rank, world, local = wdist.init_from_env(a.backend)
     if a.same_device:
         local = 0
