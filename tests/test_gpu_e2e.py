@@ -397,7 +397,8 @@ def test_vit_h_batches_golden_tile_and_bit_identity(prec, golden_dir):
         assert _nms_positions(rec, 0) == fx["pp0_nms_index"].tolist(), B
     for B in (4, 1):
         for k in ("pred_logits", "pred_boxes", "records"):
-            assert torch.equal(outs[B][k], outs[16][k][:B]), (B, k)
+            # records hold int32 fields behind a float32 view (nms_rank = -1 reads as NaN): compare the bits
+            assert torch.equal(outs[B][k].view(torch.int32), outs[16][k][:B].view(torch.int32)), (B, k)
     # every tile of the batch produced detections of its own (no tile silently copied or skipped)
     lg16 = outs[16]["pred_logits"]
     assert all(not torch.equal(lg16[i], lg16[j]) for i in range(16) for j in range(i))

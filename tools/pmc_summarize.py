@@ -2,7 +2,7 @@
 """Summarise a `rocprofv3 -i tools/pmc_traffic.txt` run (one pmc_N directory per counter pass) into the per-kernel-class
 HBM traffic JSON that bench.py reads (profiles/*_pmc_traffic.json).
 
-usage: tools/pmc_summarize.py <rocprof output dir> <out.json> "<command that was profiled>"
+usage: tools/pmc_summarize.py <rocprof output dir> <out.json> "<command that was profiled>" [batch] [precision]
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (wide
 coalesced reads are counted at half their bytes).  Averages are per launch over every launch of a class."""
@@ -22,6 +22,8 @@ def kclass(name):
 
 def main():
     root, out, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+    precision = sys.argv[5] if len(sys.argv) > 5 else "bf16"
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.defaultdict(lambda: collections.defaultdict(set))
     for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
@@ -43,8 +45,8 @@ def main():
     doc = {"command": cmd,
            "note": "separate --pmc passes for FETCH_SIZE and WRITE_SIZE (TCC slots); counters in KiB; FETCH_SIZE doubled per "
                    "MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); averages per launch over all "
-                   "launches of the class (ViT-H, B=4, bf16); produced by tools/pmc_summarize.py",
-           "classes": classes}
+                   f"launches of the class (ViT-H, B={batch}, {precision}); produced by tools/pmc_summarize.py",
+           "batch": batch, "precision": precision, "classes": classes}
     with open(out, "w") as fh:
         json.dump(doc, fh, indent=1)
     print(json.dumps(classes, indent=1))
