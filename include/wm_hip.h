@@ -36,6 +36,9 @@ extern "C" {
  * FLOPs -- always use fp16 operands, see DESIGN.md "Precision") */
 #define WM_PREC_BF16 0   /* north_star default: bf16 MFMA                         */
 #define WM_PREC_FP16 1   /* fp16 MFMA, same rate, 3 more mantissa bits */
+#define WM_PREC_FP8 2    /* BASELINE.json configs[4]: the blocks' qkv / proj / MLP GEMMs on the block-scaled fp8 MFMA
+                            (OCP e4m3 weights with one fp32 scale per output channel, e4m3 activations at unit scale,
+                            fp32 accumulation); attention stays bf16.  Tolerance re-stated in DESIGN.md section 3. */
 
 #define WM_MAX_GLOBAL 8
 #define WM_NUM_QUERIES 51   /* segment_anything/modeling/box_decoder.py:53 (50 + 1) */
@@ -201,6 +204,15 @@ int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* bias_dev,
                  const float* residual_dev, int res_mod, float* out_f32_dev, void* out_16_dev,
                  int M, int N, int K, int act, int precision, void* stream);
 
+/* fp8 (OCP e4m3) GEMM of WM_PREC_FP8, gemm8.h: C = act((A W^T) * wscale[n] + bias[n]) (+ residual).
+ * a [M,K] e4m3 (unit scale), w [N,K] e4m3, wscale [N] fp32; exactly one of: residual + out_f32 (+ out_16), out_8 (e4m3),
+ * out_16 alone.  M % 256 == 0, N % 256 == 0, K % 128 == 0, K >= 256.  precision = type of out_16 (WM_PREC_BF16 | FP16). */
+int wm_op_gemm8(const void* a_dev, const void* w_dev, const float* wscale_dev, const float* bias_dev,
+                const float* residual_dev, float* out_f32_dev, void* out_16_dev, void* out_8_dev,
+                int M, int N, int K, int act, int precision, void* stream);
+/* fp32 -> e4m3 bytes, unit scale, round to nearest even, saturating at +-448 (n % 4 == 0) */
+int wm_op_cvt_f32_to_fp8(const float* in_dev, void* out_dev, int64_t n, void* stream);
+
 /* The transformer block's two residual updates fused with the LayerNorm that follows them
  * (image_encoder.py:200-203: x = shortcut + attn(...), then norm2(x); x = x + mlp(...), then the next block's norm1):
  * out_f32 = residual + A W^T + bias (residual may alias out_f32) and out_16 = LayerNorm(out_f32 rows; gamma, beta, eps).
@@ -221,7 +233,8 @@ int wm_op_conv3x3_16(const void* a_dev, const void* w_dev, float* out_dev, int b
 int wm_op_gemm32(const float* a_dev, const float* w_dev, const float* bias_dev,
                  const float* residual_dev, float* out_dev, int M, int N, int K, int act, void* stream);
 
-/* LayerNorm over the last dim of [rows, C] fp32 (biased variance); writes fp32 and/or 16-bit. */
+/* LayerNorm over the last dim of [rows, C] fp32 (biased variance); writes fp32 and/or 16-bit
+ * (precision WM_PREC_FP8 with out_f32 NULL: e4m3 bytes into out_16, the blocks' form only). */
 int wm_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps,
                     float* out_f32_dev, void* out_16_dev, int64_t rows, int C, int precision, void* stream);
 

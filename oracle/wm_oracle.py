@@ -43,6 +43,15 @@ def bf16_round(t: Tensor) -> Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def fp16_round(t: Tensor) -> Tensor:
+    return t.clamp(-65504.0, 65504.0).to(torch.float16).to(torch.float32)
+
+
+def e4m3_round(t: Tensor) -> Tensor:
+    """OCP e4m3fn, round to nearest even, saturating at +-448 (what v_cvt_pk_fp8_f32 behind a clamp does on gfx950)."""
+    return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+
+
 @dataclass
 class OracleCfg:
     embed_dim: int = 1280
@@ -58,6 +67,10 @@ class OracleCfg:
     dec_depth: int = 2
     num_queries: int = 51
     rnd: Callable[[Tensor], Tensor] = field(default=_ident)
+    # WM_PREC_FP8 emulation (BASELINE.json configs[4]): the blocks' four projections take e4m3 activations (unit scale)
+    # and e4m3 weights with one fp32 scale per output channel; attention runs on bf16 operands; set `rnd` to fp16_round
+    # for the stem / HFC adaptor / neck, which always use fp16 operands on the GPU.
+    block_fp8: bool = False
 
     @staticmethod
     def from_model_type(model_type: str, rnd: Callable[[Tensor], Tensor] = _ident) -> "OracleCfg":
@@ -85,6 +98,18 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor], cfg: OracleCfg) -> Tensor:
     """y = x W^T + b with operands passed through cfg.rnd (fp32 accumulate)."""
     y = cfg.rnd(x) @ cfg.rnd(w).t()
     return y if b is None else y + b
+
+
+def linear8(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """y = (e4m3(x) e4m3(W / s)^T) * s + b with s[n] = max_k |W[n, k]| / 448 (gemm8.h; packer in wm_api.hip)."""
+    sw = w.abs().amax(dim=1, keepdim=True) / 448.0
+    sw = torch.where(sw > 0, sw, torch.ones_like(sw))
+    y = (e4m3_round(x) @ e4m3_round(w / sw).t()) * sw.t()
+    return y if b is None else y + b
+
+
+def block_linear(x: Tensor, w: Tensor, b: Optional[Tensor], cfg: OracleCfg) -> Tensor:
+    return linear8(x, w, b) if cfg.block_fp8 else linear(x, w, b, cfg)
 
 
 def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
@@ -219,11 +244,12 @@ def attention_rel(x: Tensor, W: Dict[str, Tensor], pre: str, heads: int, cfg: Or
     Bp, S, _, D = x.shape
     N = S * S
     hd = D // heads
-    qkv = linear(x.reshape(Bp, N, D), W[pre + "qkv.weight"], W[pre + "qkv.bias"], cfg)
-    qkv = cfg.rnd(qkv).reshape(Bp, N, 3, heads, hd).permute(2, 0, 3, 1, 4)    # (3,B',h,N,hd)
+    arnd = bf16_round if cfg.block_fp8 else cfg.rnd                            # fp8 mode: attention on the bf16 kernels
+    qkv = block_linear(x.reshape(Bp, N, D), W[pre + "qkv.weight"], W[pre + "qkv.bias"], cfg)
+    qkv = arnd(qkv).reshape(Bp, N, 3, heads, hd).permute(2, 0, 3, 1, 4)       # (3,B',h,N,hd)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    Rh = cfg.rnd(rel_pos_table(S, W[pre + "rel_pos_h"]))
-    Rw = cfg.rnd(rel_pos_table(S, W[pre + "rel_pos_w"]))
+    Rh = arnd(rel_pos_table(S, W[pre + "rel_pos_h"]))
+    Rw = arnd(rel_pos_table(S, W[pre + "rel_pos_w"]))
     scale = hd ** -0.5
     out = torch.empty(Bp, heads, N, hd)
     # head-at-a-time keeps the 4096x4096 global case inside memory
@@ -235,9 +261,11 @@ def attention_rel(x: Tensor, W: Dict[str, Tensor], pre: str, heads: int, cfg: Or
         rel_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw)                         # :377
         a = (a.view(Bp, S, S, S, S) + rel_h[..., :, None] + rel_w[..., None, :]).view(Bp, N, N)  # :379-381
         p = a.softmax(-1)
-        out[:, h] = cfg.rnd(p) @ vh
+        out[:, h] = arnd(p) @ vh
     o = out.permute(0, 2, 1, 3).reshape(Bp, N, D)
-    o = linear(o, W[pre + "proj.weight"], W[pre + "proj.bias"], cfg)
+    if cfg.block_fp8:
+        o = bf16_round(o)                                                      # the attention kernels' 16-bit output
+    o = block_linear(o, W[pre + "proj.weight"], W[pre + "proj.bias"], cfg)
     return o.reshape(Bp, S, S, D)
 
 
@@ -271,8 +299,8 @@ def encoder_block(x: Tensor, W: Dict[str, Tensor], i: int, cfg: OracleCfg) -> Te
         y = from_windows(yw, cfg.window, n, x.shape[1])
     x = x + y
     z = layer_norm(x, W[pre + "norm2.weight"], W[pre + "norm2.bias"], 1e-6)
-    z = gelu_erf(linear(z, W[pre + "mlp.lin1.weight"], W[pre + "mlp.lin1.bias"], cfg))
-    z = linear(z, W[pre + "mlp.lin2.weight"], W[pre + "mlp.lin2.bias"], cfg)
+    z = gelu_erf(block_linear(z, W[pre + "mlp.lin1.weight"], W[pre + "mlp.lin1.bias"], cfg))
+    z = block_linear(z, W[pre + "mlp.lin2.weight"], W[pre + "mlp.lin2.bias"], cfg)
     return x + z
 
 

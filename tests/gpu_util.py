@@ -99,3 +99,52 @@ def mha32(q, k, v, heads):
     out = torch.empty_like(q)
     N.check(N.lib().wm_op_mha32(N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(out), B, heads, Cc // heads, nq, nk, sp()))
     return out
+
+
+# ---- fp8 (OCP e4m3) helpers for the WM_PREC_FP8 tests ----
+def e4m3_lut(device):
+    """256-entry decode table of OCP e4m3fn (bias 7, 0x7f / 0xff = NaN, no infinity)."""
+    import math
+    vals = []
+    for b in range(256):
+        s, e, m = b >> 7, (b >> 3) & 15, b & 7
+        if e == 15 and m == 7:
+            v = float("nan")
+        elif e == 0:
+            v = m * 2.0 ** -9
+        else:
+            v = (1 + m / 8.0) * 2.0 ** (e - 7)
+        vals.append(-v if s else v)
+    return torch.tensor(vals, dtype=torch.float32, device=device)
+
+
+def to_fp8(x: torch.Tensor) -> torch.Tensor:
+    """fp32 cuda tensor -> e4m3 bytes (uint8) through the library's convert kernel (unit scale, RNE, saturating)."""
+    x = x.contiguous().float()
+    out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    N.check(N.lib().wm_op_cvt_f32_to_fp8(N.ptr(x), N.ptr(out), x.numel(), sp()))
+    return out
+
+
+def from_fp8(b: torch.Tensor) -> torch.Tensor:
+    return e4m3_lut(b.device)[b.long()]
+
+
+def quant_weight_fp8(w: torch.Tensor):
+    """Per-output-channel e4m3 quantisation as the weight packer does it: (bytes, scale[N])."""
+    sc = w.abs().amax(dim=1) / 448.0
+    sc = torch.where(sc > 0, sc, torch.ones_like(sc))
+    return to_fp8(w / sc[:, None]), sc.contiguous()
+
+
+def gemm8(a8, w8, wscale, bias=None, residual=None, act=0, mode="f32", prec="bf16"):
+    """mode: 'f32' (needs residual; returns fp32), '16' (16-bit out), '8' (e4m3 out)."""
+    code, dt = PRECS[prec]
+    M, K = a8.shape
+    Nn = w8.shape[0]
+    o32 = residual.clone() if mode == "f32" else None
+    o16 = torch.empty((M, Nn), device=a8.device, dtype=dt) if mode == "16" else None
+    o8 = torch.empty((M, Nn), device=a8.device, dtype=torch.uint8) if mode == "8" else None
+    N.check(N.lib().wm_op_gemm8(N.ptr(a8), N.ptr(w8), N.ptr(wscale), N.ptr(bias), N.ptr(o32) if mode == "f32" else None, N.ptr(o32),
+                                N.ptr(o16), N.ptr(o8), M, Nn, K, act, code, sp()))
+    return {"f32": o32, "16": o16, "8": o8}[mode]

@@ -402,3 +402,77 @@ def test_vit_h_batches_golden_tile_and_bit_identity(prec, golden_dir):
     # every tile of the batch produced detections of its own (no tile silently copied or skipped)
     lg16 = outs[16]["pred_logits"]
     assert all(not torch.equal(lg16[i], lg16[j]) for i in range(16) for j in range(i))
+
+
+# ---------------------------------------------------------------------------
+# fp8 (BASELINE.json configs[4]: "ViT-H fp8 MFMA weights/activations, batch=16 ... tolerance re-stated")
+# ---------------------------------------------------------------------------
+# Re-stated tolerance: e4m3 carries 3 mantissa bits (relative rounding error up to 2^-4 per operand
+# element), so the fp32 reference is matched to about 1e-2 on the logits instead of 1e-3, measured first with the CPU
+# emulation (oracle cfg.block_fp8: 9.0e-3 ViT-B, 1.1e-2 ViT-H).  Asserted: logits within 2.5e-2 relative of the reference
+# fixture, boxes within 2e-2 absolute, detections (score cut + NMS) scoring mAP >= 0.85 against the reference's own
+# detections; and the GPU path within 5e-3 of the CPU emulation of the same arithmetic (ViT-B).
+FP8_LOGIT_TOL, FP8_BOX_TOL, FP8_MAP_TOL = 2.5e-2, 2e-2, 0.85
+
+
+def _dets_from_records(rec, b):
+    kept = (rec["flags"][b] & 4) != 0
+    order = torch.argsort(rec["nms_rank"][b][kept])
+    return {"boxes": rec["boxes"][b][kept][order].numpy(), "scores": rec["scores"][b][kept][order].numpy(),
+            "labels": rec["labels"][b][kept][order].numpy()}
+
+
+def _fp8_vs_golden(mt, golden_dir, batch):
+    from wildlifemapper_amd import _native as Nn
+    from wildlifemapper_amd.coco_eval import map_vs_reference
+    fx = np.load(os.path.join(golden_dir, f"e2e_{mt}.npz"))
+    n = int(fx["n_tiles"])
+    m, _ = _model(mt, "fp8")
+    x = torch.from_numpy(synth.make_batch(int(fx["first_tile"]), max(batch, n))).to(G.dev())
+    ts = torch.tensor([[1024, 1024]] * x.shape[0])
+    m.detect(NestedTensor(x, None), ts)
+    Nn.gemm_variant_counts(reset=True)
+    out = {k: v.cpu() for k, v in m.detect(NestedTensor(x, None), ts).items()}
+    torch.cuda.synchronize()
+    var = {k: v for k, v in Nn.gemm_variant_counts().items() if v}
+    depth = synth.MODEL_DIMS[mt].depth
+    assert var.get("fp8_256", 0) == 4 * depth, var                      # qkv, proj, lin1, lin2 of every block on the fp8 MFMA
+    lg = out["pred_logits"][:n].numpy()
+    lerr = np.linalg.norm(lg - fx["pred_logits"]) / np.linalg.norm(fx["pred_logits"])
+    berr = np.abs(out["pred_boxes"][:n].numpy() - fx["pred_boxes"]).max()
+    rec = split_records(out["records"])
+    pred = {b: _dets_from_records(rec, b) for b in range(n)}
+    ref_pp = O.postprocess(torch.from_numpy(fx["pred_logits"]), torch.from_numpy(fx["pred_boxes"]), torch.tensor([[1024, 1024]] * n))
+    gt = {}
+    for b in range(n):
+        d = O.detect(ref_pp[b])
+        gt[b] = {"boxes": d["boxes"].numpy(), "scores": d["scores"].numpy(), "labels": d["labels"].numpy()}
+    mp = map_vs_reference(pred, gt)
+    print(f"[{mt}/fp8] B={x.shape[0]} logits={lerr:.2e} boxes_maxabs={berr:.2e} mAP vs reference detections={mp['mAP']:.3f} "
+          f"(kept {[len(pred[b]['scores']) for b in range(n)]} vs {[len(gt[b]['scores']) for b in range(n)]})  GEMM instances {var}")
+    assert lerr < FP8_LOGIT_TOL, lerr
+    assert berr < FP8_BOX_TOL, berr
+    assert mp["mAP"] >= FP8_MAP_TOL, mp
+    return out
+
+
+def test_vit_b_fp8_vs_reference_golden_and_emulation(golden_dir):
+    out = _fp8_vs_golden("vit_b", golden_dir, 2)
+    # the CPU emulation of the same arithmetic (e4m3 operands with the packer's per-channel weight scales, bf16
+    # attention, fp16 stem / neck): the kernels must be its faithful implementation, tile 0
+    m, _ = _model("vit_b", "fp8")
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    cfg = O.OracleCfg.from_model_type("vit_b", rnd=O.fp16_round)
+    cfg.block_fp8 = True
+    ref = O.model_forward(torch.from_numpy(synth.make_batch(0, 1)), sd, cfg)
+    err = G.rel_l2(out["pred_logits"][:1], ref["pred_logits"])
+    print(f"[vit_b/fp8] GPU vs CPU emulation of the fp8 arithmetic: logits={err:.2e}")
+    assert err < 5e-3, err
+
+
+def test_vit_h_fp8_batch16_vs_reference_golden(golden_dir):
+    """configs[4] literally: ViT-H, batch 16, tile 0 = the golden tile."""
+    out = _fp8_vs_golden("vit_h", golden_dir, 16)
+    lg = out["pred_logits"]
+    assert all(not torch.equal(lg[i], lg[j]) for i in range(16) for j in range(i))
+    assert bool(torch.isfinite(lg).all())

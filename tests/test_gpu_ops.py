@@ -405,3 +405,76 @@ def test_mha32(nq, nk, heads, hd):
     out = G.mha32(q, k, v, heads)
     ref = O.mha_core(q.cpu(), k.cpu(), v.cpu(), heads, O.OracleCfg())
     assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
+# ---------------------------------------------------------------------------
+# fp8 (BASELINE.json configs[4]): e4m3 converts and the block-scaled-MFMA GEMM (gemm8.h)
+# ---------------------------------------------------------------------------
+def test_fp8_convert_matches_torch_e4m3():
+    """Device f32 -> e4m3 (v_cvt_pk_fp8_f32 behind a clamp) against torch's float8_e4m3fn cast on the CPU: round to
+    nearest even, subnormals kept, saturation at 448; and the decode table against torch's."""
+    x = torch.randn(1 << 16, device=G.dev()) * torch.exp(torch.randn(1 << 16, device=G.dev()) * 3)
+    x[:16] = torch.tensor([0.0, -0.0, 1.0625, 1.1875, 447.0, 448.0, 449.0, 1e6, -1e6, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 0.0146484375,
+                           -0.017, 463.9, 2.0 ** -11], device=G.dev())
+    got = G.to_fp8(x).cpu()
+    want = x.cpu().clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert torch.equal(got, want.view(torch.uint8))
+    lut = G.e4m3_lut("cpu")
+    allb = torch.arange(256, dtype=torch.uint8)
+    ref = allb.view(torch.float8_e4m3fn).float()
+    ok = ~torch.isnan(ref)
+    assert torch.equal(lut[ok], ref[ok]) and bool(torch.isnan(lut[~ok]).all())
+
+
+def test_gemm8_identity_asymmetric():
+    """A = I against an asymmetric W (exactly representable integers) catches a wrong lane map or a transposed C write."""
+    dev = G.dev()
+    M, N, K = 256, 256, 256
+    a = torch.zeros(M, K, device=dev)
+    a[:, :K] = torch.eye(K, device=dev)[:M]
+    w = ((torch.arange(N * K, device=dev, dtype=torch.float32).reshape(N, K) * 7) % 15) - 7       # integers -7..7, asymmetric
+    a8, w8 = G.to_fp8(a), G.to_fp8(w)
+    one = torch.ones(N, device=dev)
+    out = G.gemm8(a8, w8, one, None, torch.zeros(M, N, device=dev), 0, "f32")
+    assert torch.equal(out, w[:, :M].t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (512, 768, 1280), (16384, 1280, 1280), (16384, 3840, 1280), (4096, 1280, 5120)])
+def test_gemm8_residual_fp32(M, N, K):
+    dev = G.dev()
+    a8 = G.to_fp8(torch.randn(M, K, device=dev))
+    w8, sc = G.quant_weight_fp8(torch.randn(N, K, device=dev) / math.sqrt(K))
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev) * 2 + torch.arange(M, device=dev).view(M, 1) % 61 * 0.5
+    out, var = _variants_run(lambda: G.gemm8(a8, w8, sc, bias, res, 0, "f32"))
+    assert var == {"fp8_256": 1}
+    want = res + (G.from_fp8(a8) @ G.from_fp8(w8).t()) * sc + bias
+    assert G.rel_l2(out, want) < 1e-5
+    assert (out - want).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K,act", [(256, 256, 256, 0), (16384, 3840, 1280, 0), (16384, 5120, 1280, 1), (512, 1024, 768, 2)])
+def test_gemm8_16bit_and_fp8_outputs(M, N, K, act):
+    dev = G.dev()
+    a8 = G.to_fp8(torch.randn(M, K, device=dev))
+    w8, sc = G.quant_weight_fp8(torch.randn(N, K, device=dev) / math.sqrt(K))
+    bias = torch.randn(N, device=dev)
+    y = (G.from_fp8(a8) @ G.from_fp8(w8).t()) * sc + bias
+    y = {0: y, 1: O.gelu_erf(y), 2: torch.relu(y)}[act]
+    o16 = G.gemm8(a8, w8, sc, bias, None, act, "16", "bf16")
+    assert G.rel_l2(o16.float(), y) < OUT16_TOL["bf16"]
+    o8 = G.gemm8(a8, w8, sc, bias, None, act, "8")
+    got = G.from_fp8(o8)
+    # e4m3 output: one rounding to 3 mantissa bits (relative 2^-4 worst case, 0.036 rms) of the fp32 value
+    want8 = G.from_fp8(G.to_fp8(y))
+    mism = (got != want8).float().mean().item()
+    assert mism < 2e-3, mism                              # ties / fp32 summation-order differences at rounding boundaries only
+    assert G.rel_l2(got, y) < 0.04
+
+
+def test_gemm8_rejects_bad_shapes():
+    dev = G.dev()
+    a8 = torch.zeros(256, 128, device=dev, dtype=torch.uint8)
+    w8 = torch.zeros(256, 128, device=dev, dtype=torch.uint8)
+    with pytest.raises(RuntimeError, match="gemm8"):
+        G.gemm8(a8, w8, torch.ones(256, device=dev), None, None, 0, "16")

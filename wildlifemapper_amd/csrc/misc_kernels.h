@@ -1,5 +1,7 @@
 // HBM-bound helper kernels: LayerNorm, patch gather, transposes, converts.
 #pragma once
+#include <type_traits>
+
 #include "wm_common.h"
 
 namespace wm {
@@ -68,6 +70,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // some batch sizes can use -- a tile's result must not depend on its batch neighbours.  One wave per row, 16-lane
 // group k owns column tile k (C = TN * BN, TN <= 4), 16-bit output.  grid (rows / 4), 256 threads.
 // ---------------------------------------------------------------------------
+// store 4 consecutive outputs of type T (16-bit) or, for FP8, as packed e4m3 bytes (wm_common.h)
+template <class T>
+__device__ __forceinline__ void store4_as(void* base, int64_t elem, const f32x4& y) {
+    if constexpr (std::is_same<T, FP8>::value) {
+        *(unsigned*)((unsigned char*)base + elem) = pack4_e4m3(y);
+    } else {
+        typename T::vec4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = T::from_f32(y[j]);
+        *(typename T::vec4*)((u16*)base + elem) = o;
+    }
+}
+
 template <class T, int BN>
 __global__ __launch_bounds__(256) void layernorm_tiled_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, u16* __restrict__ out16,
@@ -98,10 +113,10 @@ __global__ __launch_bounds__(256) void layernorm_tiled_kernel(const float* __res
         const int c0 = k * BN + (l16 + 16 * kk) * 4;
         const f32x4 g = *(const f32x4*)(gamma + c0);
         const f32x4 b = *(const f32x4*)(beta + c0);
-        typename T::vec4 o;
+        f32x4 y;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = T::from_f32(ln_apply(v[kk][j], mean, rstd, g[j], b[j]));
-        *(typename T::vec4*)(out16 + row * C + c0) = o;
+        for (int j = 0; j < 4; ++j) y[j] = ln_apply(v[kk][j], mean, rstd, g[j], b[j]);
+        store4_as<T>(out16, row * C + c0, y);
     }
 }
 

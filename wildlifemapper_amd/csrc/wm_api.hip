@@ -24,6 +24,7 @@
 #include "gemm16_v3.h"
 #include "gemm16_v5.h"
 #include "gemm32.h"
+#include "gemm8.h"
 #include "misc_kernels.h"
 #include "wm_common.h"
 
@@ -138,6 +139,28 @@ static inline uint16_t f32_to_f16_host(float f) {
     return r;
 }
 
+// f32 -> OCP e4m3fn (bias 7, max 448, no infinity, 0x7f = NaN), round to nearest even, saturating; weight packer of WM_PREC_FP8
+static inline uint8_t f32_to_e4m3_host(float f) {
+    if (f != f) return 0x7f;
+    const uint8_t sign = std::signbit(f) ? 0x80 : 0;
+    float a = fabsf(f);
+    if (a > 448.0f) a = 448.0f;
+    if (a == 0.0f) return sign;
+    int e;
+    (void)frexpf(a, &e);                                           // a = m 2^e, m in [0.5, 1): floor(log2 a) = e - 1
+    int fl = e - 1;
+    if (fl < -6) fl = -6;                                          // subnormals share the quantum 2^-9
+    const float q = ldexpf(1.0f, fl - 3);
+    float v = nearbyintf(a / q) * q;                               // exact scaling; default rounding mode = nearest even
+    if (v == 0.0f) return sign;
+    if (v > 448.0f) v = 448.0f;
+    if (v < ldexpf(1.0f, -6)) return sign | (uint8_t)(int)(v / ldexpf(1.0f, -9));
+    (void)frexpf(v, &e);
+    const int ex = e - 1;
+    const int man = (int)((v / ldexpf(1.0f, ex) - 1.0f) * 8.0f);
+    return sign | (uint8_t)(((ex + 7) << 3) | man);
+}
+
 // ---------------------------------------------------------------------------
 // engine
 // ---------------------------------------------------------------------------
@@ -184,6 +207,7 @@ struct LnFuseState {
 struct wm_handle {
     wm_config cfg{};
     LnFuseState lnf;
+    int fp8_bf16_tail = 0;  // fp8 mode: the last fp8_bf16_tail blocks stay bf16 (env WM_FP8_BF16_TAIL, default 0)
     int fp16_tail = 0;      // bf16 mode: the last fp16_tail transformer blocks use fp16 operands (parity margin; default depth / 4)
     int device = 0;
     int D = 0, depth = 0, heads = 0, hd = 0, prec = 0, maxB = 0;
@@ -192,6 +216,8 @@ struct wm_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // name -> shape
     std::map<std::string, HostW> staged;
     std::map<std::string, uint16_t*> w16;
+    std::map<std::string, uint8_t*> w8;     // WM_PREC_FP8: e4m3 weights of the blocks' GEMMs; their per-channel scales live in w32[name + ".wscale"]
+    uint8_t* ao8 = nullptr;                 // attention output as e4m3 (A operand of proj)
     std::map<std::string, float*> w32;
     std::vector<void*> allocs;
     Profiler prof;
@@ -533,6 +559,30 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
     return WM_BY_PREC((launch_gemm16_t<BF16>(h, s, a)), (launch_gemm16_t<FP16>(h, s, a)));
 }
 
+// fp8 GEMM (gemm8.h).  T16 = type of a 16-bit output.
+int launch_gemm8(wm_handle* h, hipStream_t s, int prec16, const void* A, const void* W, const float* wscale, const float* bias,
+                 const float* res, float* out32, void* out16, void* out8, int M, int N, int K, int act) {
+    if (M <= 0 || N <= 0 || K <= 0 || M % G8::BM || N % G8::BN || K % G8::BKB || K / G8::BKB < 2)
+        return fail("gemm8: shape M=%d N=%d K=%d must be multiples of %d/%d/%d with K >= %d", M, N, K, G8::BM, G8::BN, G8::BKB, 2 * G8::BKB);
+    if (!A || !W || !wscale) return fail("gemm8: null operand");
+    const int modes = (res != nullptr) + (out8 != nullptr) + (res == nullptr && out8 == nullptr && out16 != nullptr);
+    if (modes != 1 || (res && !out32 && !out16) || (!res && out32)) return fail("gemm8: outputs must be (residual + out32 [+ out16]) | out8 | out16");
+    Gemm8Args a{(const unsigned char*)A, (const unsigned char*)W, wscale, bias, res, out32, (u16*)out16, (unsigned char*)out8, M, N, K, act};
+    const int grid = (M / G8::BM) * (N / G8::BN);
+    count_variant(WM_GEMM_FP8_256);
+    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * M * (double)N * K,
+               (double)M * K + (double)N * K + (res ? 8.0 : 0.0) * M * N + (out16 ? 2.0 : 0.0) * M * N + (out8 ? 1.0 : 0.0) * M * N);
+    if (prec16 == WM_PREC_FP16) {
+        WM_TRY(set_max_lds((const void*)gemm8_kernel<FP16>, G8::LDS));
+        hipLaunchKernelGGL((gemm8_kernel<FP16>), dim3(grid), dim3(512), G8::LDS, s, a);
+    } else {
+        WM_TRY(set_max_lds((const void*)gemm8_kernel<BF16>, G8::LDS));
+        hipLaunchKernelGGL((gemm8_kernel<BF16>), dim3(grid), dim3(512), G8::LDS, s, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // 3x3 / pad 1 convolution over an NHWC [B,64,64,C] 16-bit activation as an implicit GEMM (no im2col buffer):
 // out[M = B*4096, N] = conv(A) with W packed [N][tap][C]  (image_encoder.py:113-119)
 int launch_conv3x3_16(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, float* out32, int M, int N, int Cin) {
@@ -587,10 +637,14 @@ int launch_layernorm(wm_handle* h, hipStream_t s, int prec, const float* x, cons
 int launch_layernorm_block(wm_handle* h, hipStream_t s, int prec, const float* x, const float* g, const float* b, float eps,
                            void* out16, int64_t rows, int C) {
     const int bn = C % 320 == 0 ? 320 : (C % 256 == 0 ? 256 : 0);
+    if ((!bn || C / bn > 4) && prec == WM_PREC_FP8) return fail("layernorm: C=%d has no e4m3 form", C);
     if (!bn || C / bn > 4) return launch_layernorm(h, s, prec, x, g, b, eps, nullptr, out16, rows, C);
     const dim3 grid((unsigned)((rows + 3) / 4));
-    Bracket br(h, s, WM_KCLASS_LAYERNORM, 0.0, (double)rows * C * 6.0);
-    if (bn == 320) {
+    Bracket br(h, s, WM_KCLASS_LAYERNORM, 0.0, (double)rows * C * (prec == WM_PREC_FP8 ? 5.0 : 6.0));
+    if (prec == WM_PREC_FP8) {
+        if (bn == 320) hipLaunchKernelGGL((layernorm_tiled_kernel<FP8, 320>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
+        else hipLaunchKernelGGL((layernorm_tiled_kernel<FP8, 256>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
+    } else if (bn == 320) {
         if (prec == WM_PREC_FP16) hipLaunchKernelGGL((layernorm_tiled_kernel<FP16, 320>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
         else hipLaunchKernelGGL((layernorm_tiled_kernel<BF16, 320>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
     } else {
@@ -797,7 +851,18 @@ void build_expected(wm_handle* h) {
 // "Precision").  The transformer blocks use the handle's precision (bf16 by default).
 // precision of transformer block i
 static int block_prec(const wm_handle* h, int i) {
+    if (h->prec == WM_PREC_FP8) return i >= h->depth - h->fp8_bf16_tail ? WM_PREC_BF16 : WM_PREC_FP8;
     return (h->prec == WM_PREC_BF16 && i >= h->depth - h->fp16_tail) ? WM_PREC_FP16 : h->prec;
+}
+static bool is_fp8_block_gemm(const wm_handle* h, const std::string& name) {
+    const std::string pre = "image_encoder.blocks.";
+    if (h->prec != WM_PREC_FP8 || name.rfind(pre, 0) != 0) return false;
+    if (block_prec(h, atoi(name.c_str() + pre.size())) != WM_PREC_FP8) return false;
+    for (const char* suf : {"attn.qkv.weight", "attn.proj.weight", "mlp.lin1.weight", "mlp.lin2.weight"}) {
+        const size_t n = strlen(suf);
+        if (name.size() >= n && name.compare(name.size() - n, n, suf) == 0) return true;
+    }
+    return false;
 }
 static bool is_fp16_block(const wm_handle* h, const std::string& name) {
     const std::string pre = "image_encoder.blocks.";
@@ -818,6 +883,28 @@ int upload16(wm_handle* h, const std::string& key, const float* src, size_t n) {
     WM_TRY(dalloc(h, &d, n * 2));
     HIP_TRY(hipMemcpy(d, tmp.data(), n * 2, hipMemcpyHostToDevice));
     h->w16[key] = d;
+    return 0;
+}
+
+// [N][K] fp32 -> e4m3 with one fp32 scale per output channel (absmax / 448), gemm8.h
+int upload8(wm_handle* h, const std::string& key, const float* src, size_t rows, size_t cols) {
+    std::vector<uint8_t> q(rows * cols);
+    std::vector<float> sc(rows);
+    for (size_t r = 0; r < rows; ++r) {
+        float amax = 0.f;
+        for (size_t c = 0; c < cols; ++c) amax = fmaxf(amax, fabsf(src[r * cols + c]));
+        const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+        sc[r] = scale;
+        for (size_t c = 0; c < cols; ++c) q[r * cols + c] = f32_to_e4m3_host(src[r * cols + c] / scale);
+    }
+    uint8_t* d = nullptr;
+    WM_TRY(dalloc(h, &d, rows * cols));
+    HIP_TRY(hipMemcpy(d, q.data(), rows * cols, hipMemcpyHostToDevice));
+    h->w8[key] = d;
+    float* ds = nullptr;
+    WM_TRY(dalloc(h, &ds, rows * 4));
+    HIP_TRY(hipMemcpy(ds, sc.data(), rows * 4, hipMemcpyHostToDevice));
+    h->w32[key + ".wscale"] = ds;
     return 0;
 }
 
@@ -847,7 +934,7 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     if (cfg->embed_dim % 256 || cfg->embed_dim > 1280) return fail("wm_create: embed_dim %d unsupported (multiple of 256, <= 1280)", cfg->embed_dim);
     const int hd = cfg->embed_dim / cfg->num_heads;
     if (hd != 64 && hd != 80) return fail("wm_create: head_dim %d unsupported (64 or 80)", hd);
-    if (cfg->precision != WM_PREC_BF16 && cfg->precision != WM_PREC_FP16) return fail("wm_create: bad precision");
+    if (cfg->precision != WM_PREC_BF16 && cfg->precision != WM_PREC_FP16 && cfg->precision != WM_PREC_FP8) return fail("wm_create: bad precision");
     if (cfg->num_global < 0 || cfg->num_global > WM_MAX_GLOBAL) return fail("wm_create: bad num_global");
     HIP_TRY(hipSetDevice(device));
     wm_handle* h = new wm_handle();
@@ -855,6 +942,7 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     // bf16 mode: the last depth/4 blocks use fp16 operands (nothing after them averages their rounding error out): logits
     // margin against the 1e-3 bar 8.3e-4 -> 6.6e-4 (ViT-H), 9.2e-4 -> 7.4e-4 (ViT-L) for ~1 % of throughput; WM_FP16_TAIL=K overrides
     h->fp16_tail = getenv("WM_FP16_TAIL") ? atoi(getenv("WM_FP16_TAIL")) : cfg->depth / 4;
+    h->fp8_bf16_tail = getenv("WM_FP8_BF16_TAIL") ? atoi(getenv("WM_FP8_BF16_TAIL")) : 0;
     h->D = cfg->embed_dim; h->depth = cfg->depth; h->heads = cfg->num_heads; h->hd = hd;
     h->prec = cfg->precision; h->maxB = cfg->max_batch;
     for (int i = 0; i < cfg->num_global; ++i) {
@@ -875,6 +963,7 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     A(pt32, BT * HFC * 4); A(y1, BT * HFC * 4); A(y1n32, BT * HFC * 4); A(z32, BT * HFC * 4);
     A(n1, BT * OUTC * 4); A(n2, BT * OUTC * 4); A(emb_nhwc, BT * OUTC * 4); A(emb_nchw, BT * OUTC * 4);
     A(n1n16, BT * OUTC * 2); A(x16last, BT * D * 2);
+    if (cfg->precision == WM_PREC_FP8) { A(ao8, BT * D); }
     A(dkeys, BT * OUTC * 4); A(dk_a, BT * 128 * 4); A(dk_b, BT * 128 * 4); A(dk_c, BT * 128 * 4);
     A(dq, B * NQ * OUTC * 4); A(dt_q, B * NQ * OUTC * 4); A(dt_k, B * NQ * OUTC * 4); A(dt_v, B * NQ * OUTC * 4);
     A(dt_att, B * NQ * OUTC * 4); A(dt_hid, B * NQ * DEC_MLP * 4); A(dt_h1, B * NQ * OUTC * 4); A(dt_h2, B * NQ * OUTC * 4);
@@ -944,7 +1033,7 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
         for (auto& kv : h->expected) {
             const bool enc = kv.first.rfind("image_encoder.", 0) == 0;
             if ((grp == 0) != enc) continue;
-            if (h->staged.count(kv.first) || h->w16.count(kv.first) || h->w32.count(kv.first)) { ++nhave; continue; }
+            if (h->staged.count(kv.first) || h->w16.count(kv.first) || h->w32.count(kv.first) || h->w8.count(kv.first)) { ++nhave; continue; }
             if (nmiss < 4) missing += (nmiss ? ", " : "") + kv.first;
             ++nmiss;
         }
@@ -961,6 +1050,10 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
         if (i16 != h->w16.end()) { hipFree(i16->second); for (auto& a : h->allocs) if (a == i16->second) a = nullptr; h->w16.erase(i16); }
         auto i32 = h->w32.find(kv.first);
         if (i32 != h->w32.end()) { hipFree(i32->second); for (auto& a : h->allocs) if (a == i32->second) a = nullptr; h->w32.erase(i32); }
+        auto i8 = h->w8.find(kv.first);
+        if (i8 != h->w8.end()) { hipFree(i8->second); for (auto& a : h->allocs) if (a == i8->second) a = nullptr; h->w8.erase(i8); }
+        auto isc = h->w32.find(kv.first + ".wscale");
+        if (isc != h->w32.end()) { hipFree(isc->second); for (auto& a : h->allocs) if (a == isc->second) a = nullptr; h->w32.erase(isc); }
     }
     const int D = h->D;
     for (auto& kv : h->staged) {
@@ -983,6 +1076,8 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
             for (int c = 0; c < HFC; ++c)
                 for (int p = 0; p < T; ++p) t[(size_t)p * HFC + c] = w.data[(size_t)c * T + p];
             WM_TRY(upload32(h, name, t.data(), n));
+        } else if (is_gemm_w && is_fp8_block_gemm(h, name)) {
+            WM_TRY(upload8(h, name, w.data.data(), (size_t)w.shape[0], n / (size_t)w.shape[0]));
         } else if (is_gemm_w) {
             WM_TRY(upload16(h, name, w.data.data(), n));
         } else {
@@ -1095,6 +1190,28 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     for (int i = 0; i < h->depth; ++i) {
         const std::string b = e + "blocks." + std::to_string(i) + ".";
         const int P = block_prec(h, i);
+        if (P == WM_PREC_FP8) {
+            // BASELINE.json configs[4]: the four projections on the fp8 MFMA (gemm8.h), e4m3 activations from the LayerNorm /
+            // convert / GELU epilogues, attention on the bf16 kernels
+            auto W8 = [&](const std::string& n) { return h->w8.at(n); };
+            WM_TRY(launch_layernorm_block(h, s, P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D));
+            WM_TRY(launch_gemm8(h, s, WM_PREC_BF16, h->xn16, W8(b + "attn.qkv.weight"), W32(h, b + "attn.qkv.weight.wscale"), W32(h, b + "attn.qkv.bias"),
+                                nullptr, nullptr, h->qkv16, nullptr, M, 3 * D, D, ACT_NONE));
+            WM_TRY(launch_encoder_attention(h, s, WM_PREC_BF16, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
+                                            W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14));
+            WM_TRY(launch_simple(h, s, (double)M * D * 3.0, cvt_16_to_fp8_kernel<BF16>, dim3(grid_for((int64_t)M * D / 8)), dim3(256), (const u16*)h->ao16,
+                                 (unsigned char*)h->ao8, (int64_t)M * D / 8));
+            WM_TRY(launch_gemm8(h, s, WM_PREC_BF16, h->ao8, W8(b + "attn.proj.weight"), W32(h, b + "attn.proj.weight.wscale"), W32(h, b + "attn.proj.bias"),
+                                h->resid, h->resid, nullptr, nullptr, M, D, D, ACT_NONE));
+            WM_TRY(launch_layernorm_block(h, s, P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D));
+            WM_TRY(launch_gemm8(h, s, WM_PREC_BF16, h->xn16, W8(b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.weight.wscale"), W32(h, b + "mlp.lin1.bias"),
+                                nullptr, nullptr, nullptr, h->hid16, M, 4 * D, D, ACT_GELU));
+            WM_TRY(launch_gemm8(h, s, WM_PREC_BF16, h->hid16, W8(b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.weight.wscale"), W32(h, b + "mlp.lin2.bias"),
+                                h->resid, h->resid, nullptr, nullptr, M, D, 4 * D, ACT_NONE));
+            xn_ready = false;
+            WM_TRY(do_tap(h, s, i, B));
+            continue;
+        }
         if (!xn_ready)
             WM_TRY(launch_layernorm_block(h, s, P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D));
         WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "attn.qkv.weight"), W32(h, b + "attn.qkv.bias"), nullptr, 0, nullptr,
@@ -1381,6 +1498,19 @@ extern "C" int wm_op_gemm16_ln(const void* a_dev, const void* w_dev, const float
     if (r == 1) return fail("wm_op_gemm16_ln: M=%d N=%d K=%d cannot be fused (M %% 256, N %% 320 or 256, <= 8 column tiles, row blocks co-resident)", M, N, K);
     if (r) return r;
     return ln_fuse_check(nullptr, (hipStream_t)stream);
+}
+
+extern "C" int wm_op_gemm8(const void* a_dev, const void* w_dev, const float* wscale_dev, const float* bias_dev, const float* residual_dev,
+                           float* out_f32_dev, void* out_16_dev, void* out_8_dev, int M, int N, int K, int act, int precision, void* stream) {
+    return launch_gemm8(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, wscale_dev, bias_dev, residual_dev, out_f32_dev, out_16_dev, out_8_dev,
+                        M, N, K, act);
+}
+
+extern "C" int wm_op_cvt_f32_to_fp8(const float* in_dev, void* out_dev, int64_t n, void* stream) {
+    if (n % 4) return fail("cvt fp8: n must be a multiple of 4");
+    hipLaunchKernelGGL(cvt_f32_to_fp8_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, in_dev, (unsigned char*)out_dev, n / 4);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 extern "C" int wm_op_conv3x3_16(const void* a_dev, const void* w_dev, float* out_dev, int batch, int c_out, int c_in, int precision,

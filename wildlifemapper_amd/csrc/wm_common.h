@@ -52,6 +52,16 @@ struct FP16 {
     }
 };
 
+// e4m3 (OCP fp8, gfx950's native fp8) activations of WM_PREC_FP8: unit scale, round to nearest even, saturating at +-448
+// (e4m3fn has no infinity).  4 floats -> 4 packed bytes.
+struct FP8 {};
+__device__ __forceinline__ unsigned pack4_e4m3(f32x4 v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], -448.0f, 448.0f);
+    unsigned r = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0u, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], r, true);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

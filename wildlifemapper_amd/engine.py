@@ -27,7 +27,7 @@ class EngineHub:
         self.global_attn_indexes = tuple(int(i) for i in global_attn_indexes)
         self.precision = (precision or default_precision()).lower()
         if self.precision not in N.PREC_BY_NAME:
-            raise ValueError(f"unknown precision {self.precision!r} (bf16 | fp16)")
+            raise ValueError(f"unknown precision {self.precision!r} (bf16 | fp16 | fp8)")
         self.max_batch = int(max_batch or os.environ.get("WM_MAX_BATCH", 0) or 0)
         self.fuse_ln = os.environ.get("WM_LN_FUSE", "0") == "1"    # wm_config.flags & WM_CFG_FUSE_LN; set before the first forward
         self._handle: Optional[C.c_void_p] = None
