@@ -268,8 +268,8 @@ def main() -> None:
                                     f", {a.precision} MFMA, batch={B} tiles/GPU of 1024x1024x3 ({_config_name(a, B, world)})"),
                        "tiles_per_step": n_tiles, "parallelism": f"dp{world} tile shard" + (f", {'RCCL' if a.backend == 'nccl' else a.backend} all-gather of box records" if world > 1 and a.workload == "full" else ""),
                        "weights": "seed 0 synthetic (random init)",
-                       "tolerance": ("re-stated for fp8 (DESIGN.md section 3): logits within 2.5e-2 relative of the fp32 CPU forward, mAP vs the CPU "
-                                     "reference's detections >= 0.85" if a.precision == "fp8"
+                       "tolerance": ("re-stated for fp8 (DESIGN.md section 3): logits within 5e-2 relative of the fp32 CPU forward, mAP50 vs the CPU "
+                                     "reference's detections >= 0.8" if a.precision == "fp8"
                                      else "logits within 1e-3 relative of the fp32 CPU forward, identical NMS index lists")},
             "model_tflops": round(tiles_per_s * flops_tile / 1e12, 1) if flops_tile else None,
             "frac_of_mfma_peak_whole_path": round(tiles_per_s * flops_tile / 1e12 / (PEAK_TFLOPS.get(a.precision, 2500.0) * world), 4) if flops_tile else None,
