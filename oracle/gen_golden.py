@@ -238,6 +238,21 @@ def gen_e2e(out: str, model_type: str, n_tiles: int, first_tile: int) -> None:
           "kept:", [len(fx[f'pp{b}_nms_index']) for b in range(n_tiles)])
 
 
+def gen_coco_subset(out: str, n_images: int = 8) -> None:
+    """Data fixture for the COCO bbox evaluator: the first images of the reference's own annotation file
+    (coco_annotations/val.json: 6 categories, xywh boxes, area, iscrowd) with their annotations, verbatim."""
+    import json
+    with open("/root/reference/coco_annotations/val.json") as f:
+        d = json.load(f)
+    imgs = d["images"][:n_images]
+    ids = {i["id"] for i in imgs}
+    sub = {"info": d.get("info", {}), "images": imgs, "categories": d["categories"],
+           "annotations": [a for a in d["annotations"] if a["image_id"] in ids]}
+    with open(os.path.join(out, "coco_val_subset.json"), "w") as f:
+        json.dump(sub, f)
+    print("wrote coco_val_subset.json:", len(imgs), "images,", len(sub["annotations"]), "annotations")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -247,6 +262,8 @@ def main() -> None:
     torch.set_num_threads(os.cpu_count() or 1)
     if a.only in ("all", "small"):
         gen_small(a.out)
+    if a.only in ("all", "coco"):
+        gen_coco_subset(a.out)
     if a.only in ("all", "vit_b"):
         gen_e2e(a.out, "vit_b", n_tiles=2, first_tile=0)
     if a.only in ("all", "vit_h"):

@@ -71,3 +71,81 @@ def test_bench_gpus_n_self_launches_child_ranks():
     assert r.returncode != 0
     assert "needs a ROCm device" in r.stderr, r.stderr[-2000:]
     assert '"n_gpus"' not in r.stdout
+
+
+# ---------------------------------------------------------------------------
+# evaluate() itself over 2 ranks (inference.py:30-89 + the rank merge of :240-259), model and PostProcess stubbed
+# ---------------------------------------------------------------------------
+def _stub_eval(rank, world):
+    """Runs wildlifemapper_amd.inference.evaluate on this rank's share of the COCO fixture; returns (stats, evaluator)."""
+    import json
+    from types import SimpleNamespace
+    import numpy as np
+    from wildlifemapper_amd.inference import evaluate
+    from wildlifemapper_amd.segment_anything.utils.misc import NestedTensor
+    ds = json.load(open(os.path.join(ROOT, "tests", "golden", "coco_val_subset.json")))
+    ids = [im["id"] for im in ds["images"]]
+    mine = ids[rank::world] + (ids[:1] if rank == 1 else [])       # rank 1 repeats an image (DistributedSampler padding)
+    by_img = {}
+    for a in ds["annotations"]:
+        by_img.setdefault(a["image_id"], []).append(a)
+
+    class Model(torch.nn.Module):
+        def forward(self, image, boxes):
+            return {"n": image.tensors.shape[0]}
+
+    class Post:
+        def __init__(self):
+            self.cur = None
+
+        def __call__(self, outputs, sizes):
+            out = []
+            for img in self.cur:
+                rng = np.random.default_rng(img)                   # deterministic per image, whatever rank evaluates it
+                anns = by_img.get(img, [])
+                b = np.array([[a["bbox"][0], a["bbox"][1], a["bbox"][0] + a["bbox"][2], a["bbox"][1] + a["bbox"][3]] for a in anns], np.float32).reshape(-1, 4)
+                keep = rng.random(len(b)) < 0.85
+                b = b[keep] + rng.normal(0, 1.5, (int(keep.sum()), 4)).astype(np.float32)
+                out.append({"boxes": torch.from_numpy(b), "scores": torch.from_numpy(rng.random(len(b)).astype(np.float32)),
+                            "labels": torch.tensor([a["category_id"] for a, k in zip(anns, keep) if k], dtype=torch.int64)})
+            return out
+
+    post = Post()
+
+    def loader():
+        for img in mine:
+            post.cur = [img]
+            yield NestedTensor(torch.zeros(1, 3, 8, 8), None), [{"image_id": torch.tensor([img]), "orig_size": torch.tensor([3648, 5472])}]
+
+    return evaluate(Model(), None, {"bbox": post}, loader(), ds, torch.device("cpu"), SimpleNamespace(batch_size=1))
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    stats, ev = _stub_eval(rank, world)
+    q.put((rank, stats, list(ev.img_ids)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluate_two_ranks_matches_single_process():
+    """The reference contract (stats, coco_evaluator) with stats['coco_eval_bbox'] = 12 numbers, and the rank merge by
+    fixed-size records: 2 gloo ranks (one of them holding a duplicate image) give exactly the single-process numbers."""
+    single, ev = _stub_eval(0, 1)
+    assert len(single["coco_eval_bbox"]) == 12 and single["images"] == 8
+    assert ev.coco_eval["bbox"].stats.tolist() == single["coco_eval_bbox"] and 0.2 < single["coco_eval_bbox"][0] <= 1.0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, stats, img_ids in got:
+        assert stats["coco_eval_bbox"] == pytest.approx(single["coco_eval_bbox"], abs=1e-12), rank
+        assert img_ids == sorted(ev.img_ids)
+        assert stats["images"] == 9                                  # 8 + the duplicate, summed over ranks as processed

@@ -281,27 +281,33 @@ def test_fused_layernorm_option_is_bit_identical():
 
 
 def test_evaluate_harness(golden_dir):
-    """inference.evaluate (inference.py:30-89): loader of (NestedTensor, targets) -> per-image detections,
-    checked against PostProcess of the golden logits."""
+    """inference.evaluate (inference.py:30-89): loader of (NestedTensor, targets) -> (stats, coco_evaluator) with
+    stats['coco_eval_bbox'] (12 COCO numbers).  Ground truth = the detections PostProcess derives from the reference's own
+    logits (golden fixture), so the HIP path must score AP = 1 against it; one image gets no ground truth at all."""
     from types import SimpleNamespace
     from wildlifemapper_amd.inference import evaluate
     from wildlifemapper_amd.segment_anything.build_sam import InferenceCriterion
     fx = np.load(os.path.join(golden_dir, "e2e_vit_b.npz"))
     m, post = _model("vit_b", "fp16")
     x = torch.from_numpy(synth.make_batch(0, 2))
-    loader = []
+    ref = O.postprocess(torch.from_numpy(fx["pred_logits"]), torch.from_numpy(fx["pred_boxes"]), torch.tensor([[1024, 1024]] * 2))
+    anns, loader = [], []
     for i in range(2):
         tgt = [{"image_id": torch.tensor([100 + i]), "orig_size": torch.tensor([1024, 1024])}]
         loader.append((nested_tensor_from_tensor_list([x[i]]), tgt))
-    stats, dets = evaluate(m, InferenceCriterion(), {"bbox": post}, loader, None, G.dev(), SimpleNamespace(batch_size=1))
-    assert stats["images"] == 2 and set(dets) == {100, 101}
-    ref = O.postprocess(torch.from_numpy(fx["pred_logits"]), torch.from_numpy(fx["pred_boxes"]), torch.tensor([[1024, 1024]] * 2))
-    for i in range(2):
-        d = dets[100 + i]
-        assert len(d["scores"]) == len(ref[i]["scores"])
-        np.testing.assert_allclose(d["scores"].numpy(), ref[i]["scores"].numpy(), atol=2e-4)
-        np.testing.assert_array_equal(d["labels"].numpy(), ref[i]["labels"].numpy())
-        np.testing.assert_allclose(d["boxes"].numpy(), ref[i]["boxes"].numpy(), atol=0.2)
+        for b, l in zip(ref[i]["boxes"].numpy(), ref[i]["labels"].numpy()):
+            anns.append({"id": len(anns) + 1, "image_id": 100 + i, "category_id": int(l), "iscrowd": 0,
+                         "bbox": [float(b[0]), float(b[1]), float(b[2] - b[0]), float(b[3] - b[1])], "area": float((b[2] - b[0]) * (b[3] - b[1]))})
+    base_ds = {"images": [{"id": 100}, {"id": 101}], "categories": [{"id": c} for c in range(7)], "annotations": anns}
+    stats, ev = evaluate(m, InferenceCriterion(), {"bbox": post}, loader, base_ds, G.dev(), SimpleNamespace(batch_size=1))
+    assert stats["images"] == 2 and ev.img_ids == [100, 101]
+    assert len(stats["coco_eval_bbox"]) == 12 and stats["coco_eval_bbox"] == ev.coco_eval["bbox"].stats.tolist()
+    print("[evaluate] coco_eval_bbox =", [round(v, 4) for v in stats["coco_eval_bbox"]])
+    assert stats["coco_eval_bbox"][0] > 0.99 and stats["coco_eval_bbox"][1] > 0.999        # fp16 path vs the fp32 reference's own detections
+    assert stats["detections"] == sum(len(r["scores"]) for r in ref)
+    # no ground truth handed over: the reference's `coco_evaluator is None` branches
+    stats2, ev2 = evaluate(m, None, {"bbox": post}, loader, None, G.dev(), SimpleNamespace(batch_size=1))
+    assert ev2 is None and "coco_eval_bbox" not in stats2 and stats2["images"] == 2
 
 
 def test_input_pipeline_bit_exact():

@@ -54,6 +54,9 @@ struct Gemm16Args {
     float* ln_stats;
     int* ln_counter;
     int ln_epoch;
+    // row tiles per group of the grouped tile order (gemm16_v5.h; 0 = G16_GROUP_M): a group's row tiles x all column tiles
+    // are consecutive tile ids, so group_m * tilesN ~ the 32 workgroups co-resident on an XCD keeps each A panel to one XCD
+    int group_m;
 };
 
 template <class T>

@@ -57,10 +57,11 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     {
         const int tilesM = p.M / C::BM, tilesN = p.N / BN;
         const int t = xcd_remap(blockIdx.x, gridDim.x);
-        const int per_group = G16_GROUP_M * tilesN;
+        const int gm = p.group_m > 0 ? p.group_m : G16_GROUP_M;
+        const int per_group = gm * tilesN;
         const int group = t / per_group;
-        const int first_m = group * G16_GROUP_M;
-        const int gsz = min(G16_GROUP_M, tilesM - first_m);
+        const int first_m = group * gm;
+        const int gsz = min(gm, tilesM - first_m);
         const int in_group = t - group * per_group;
         m0 = (first_m + in_group % gsz) * C::BM;
         n0 = (in_group / gsz) * BN;

@@ -327,14 +327,24 @@ int launch_gemm16v3_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     return 0;
 }
 
+// Row tiles per group of the staggered kernel's tile order (Gemm16Args::group_m).  WM_GEMM_GROUP_M=n overrides (A/B runs).
+static int gemm_group_m(int tilesM, int tilesN) {
+    const char* e = getenv("WM_GEMM_GROUP_M");
+    if (e && atoi(e) > 0) return atoi(e);
+    (void)tilesM; (void)tilesN;
+    return G16_GROUP_M;
+}
+
 template <class T16, int BN, int NSLOT = 3>
-int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
+int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
     using G = G3<BN, 4>;
     constexpr int LDS = NSLOT * G::STAGE + 32 * BN * 4;        // ring + the first residual landing buffer
     static_assert(LDS <= 160 * 1024, "LDS");
     WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, NSLOT>, LDS));
-    count_variant(BN == 320 ? (a.residual ? WM_GEMM_V5_320_RES : WM_GEMM_V5_320) : (a.residual ? WM_GEMM_V5_256_RES : WM_GEMM_V5_256));
-    const int grid = (a.M / 256) * (a.N / BN);
+    count_variant(BN == 320 ? (a_in.residual ? WM_GEMM_V5_320_RES : WM_GEMM_V5_320) : (a_in.residual ? WM_GEMM_V5_256_RES : WM_GEMM_V5_256));
+    const int grid = (a_in.M / 256) * (a_in.N / BN);
+    Gemm16Args a = a_in;
+    a.group_m = gemm_group_m(a.M / 256, a.N / BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
     if constexpr (BN == 320 && NSLOT == 3) {
