@@ -107,6 +107,19 @@ int wm_finalize_weights(wm_handle* h);
  * padding to 1024 x 1024 of segment_anything/utils/misc.py:46-67 (the resize to 768 is not part of it). */
 int wm_preprocess_u8(const uint8_t* img_dev, float* out_dev, int batch, int height, int width, void* stream);
 
+/* The same with the val transform's resize in front (dataloader_coco.py:286-292: T.RandomResize([size], max_size) ->
+ * segment_anything/utils/augmentation.py:77-133 -> torchvision F.resize on a PIL image): frames [B,height,width,3] u8 of
+ * any size are resampled to (oh, ow) = wm_resized_size(...) with Pillow's 8-bit bilinear resample arithmetic
+ * (antialiased triangle filter, 22-bit fixed-point coefficients, horizontal then vertical pass; bit-exact with
+ * PIL.Image.resize, tests/golden/resize_pil.npz), then ToTensor + Normalize + zero padding to 1024 x 1024.  Coefficient
+ * tables and the intermediate image are cached by the library per device and geometry.  (oh, ow) must fit the canvas. */
+int wm_preprocess_u8_resized(const uint8_t* img_dev, float* out_dev, int batch, int height, int width, int size, int max_size,
+                             void* stream);
+/* augmentation.py:80-99 get_size_with_aspect_ratio: the (oh, ow) the resize above produces */
+int wm_resized_size(int height, int width, int size, int max_size, int* out_h, int* out_w);
+/* host-only (tests): the fixed-point coefficient tables of one axis, bounds [out_size][2], kk [out_size][*ksize_out] */
+int wm_debug_resize_coeffs(int in_size, int out_size, int* bounds_out, int* kk_out, int kk_capacity, int* ksize_out);
+
 /* MedSAM.fft, segment_anything/network.py:36-57.
  * x (B,3,1024,1024) fp32 -> hfc (B,1,1024,1024) fp32. */
 int wm_hfc_fft(wm_handle* h, const float* x_dev, float* hfc_dev, int batch, void* stream);

@@ -253,6 +253,29 @@ def gen_coco_subset(out: str, n_images: int = 8) -> None:
     print("wrote coco_val_subset.json:", len(imgs), "images,", len(sub["annotations"]), "annotations")
 
 
+def gen_resize(out: str) -> None:
+    """Golden vectors of the val transform's resize (dataloader_coco.py:288 -> augmentation.py:77-133 ->
+    torchvision F.resize on a PIL image = PIL.Image.resize(BILINEAR)): inputs and PIL's own outputs, small cases
+    (down-scaling with the antialiasing filter at several ratios, up-scaling, one axis unchanged)."""
+    from PIL import Image
+    import PIL
+    from oracle import pil_resize as R
+    rng = np.random.default_rng(11)
+    fx = {"pillow_version": np.array(PIL.__version__)}
+    cases = [(150, 225, 64, 64), (40, 60, 64, 96), (182, 273, 48, 48), (64, 48, 96, 128), (114, 171, 24, 24), (100, 150, 65, 65), (64, 64, 64, 64)]
+    fx["cases"] = np.array(cases, dtype=np.int32)
+    for i, (h, w, size, mx) in enumerate(cases):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if i == 2:                                   # smooth content too, not only noise
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = np.stack([(yy * 255 // h), (xx * 255 // w), ((yy + xx) % 256)], axis=-1).astype(np.uint8)
+        oh, ow = R.get_size_with_aspect_ratio((w, h), size, mx)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+        fx[f"in{i}"], fx[f"out{i}"] = img, ref
+    np.savez_compressed(os.path.join(out, "resize_pil.npz"), **fx)
+    print("wrote resize_pil.npz", sum(v.nbytes for v in fx.values()) // 1024, "KiB (Pillow", PIL.__version__ + ")")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -262,6 +285,8 @@ def main() -> None:
     torch.set_num_threads(os.cpu_count() or 1)
     if a.only in ("all", "small"):
         gen_small(a.out)
+    if a.only in ("all", "resize"):
+        gen_resize(a.out)
     if a.only in ("all", "coco"):
         gen_coco_subset(a.out)
     if a.only in ("all", "vit_b"):

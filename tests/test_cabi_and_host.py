@@ -124,3 +124,29 @@ def test_build_sam_checkpoint_filter(tmp_path):
     torch.save({"model": sd, "epoch": 3}, path)
     sam2, _, _ = build_sam_vit_b(str(path), None)
     assert float(sam2.state_dict()["image_encoder.pos_embed"].mean()) == 0.25
+
+
+def test_resize_size_rule_and_coefficients_match_pil_restatement():
+    """Host side of the N1 resize (no GPU): the output-size rule (augmentation.py:80-99) and the 22-bit fixed-point
+    coefficient tables (Pillow Resample.c) computed by the library equal the oracle's restatement, which the PIL-generated
+    fixture pins (tests/test_oracle_small.py::test_pil_resize_restatement)."""
+    import ctypes as C
+    from oracle import pil_resize as R
+    from wildlifemapper_amd.preprocess import resized_size
+    rng = np.random.default_rng(0)
+    sizes = [(3648, 5472), (4000, 6000), (5472, 3648), (1000, 1000), (768, 768), (767, 1023), (1, 5), (333, 334)]
+    sizes += [tuple(int(v) for v in rng.integers(1, 7000, 2)) for _ in range(200)]
+    for h, w in sizes:
+        for size, mx in ((768, 768), (512, 1333), (64, 96)):
+            assert resized_size(h, w, size, mx) == R.get_size_with_aspect_ratio((w, h), size, mx), (h, w, size, mx)
+    lib = N.lib()
+    for n_in, n_out in [(5472, 768), (3648, 512), (225, 64), (60, 96), (100, 100), (7, 3), (6000, 768), (4000, 512)]:
+        b_ref, k_ref, ks_ref = R.precompute_coeffs(n_in, n_out)
+        cap = n_out * ks_ref
+        b = (C.c_int * (2 * n_out))()
+        k = (C.c_int * cap)()
+        ks = C.c_int()
+        N.check(lib.wm_debug_resize_coeffs(n_in, n_out, b, k, cap, C.byref(ks)))
+        assert ks.value == ks_ref
+        assert np.array_equal(np.frombuffer(b, dtype=np.int32).reshape(n_out, 2), b_ref)
+        assert np.array_equal(np.frombuffer(k, dtype=np.int32).reshape(n_out, ks_ref), k_ref)

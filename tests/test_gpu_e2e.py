@@ -485,3 +485,33 @@ def test_vit_h_fp8_batch16_vs_reference_golden(golden_dir):
     lg = out["pred_logits"]
     assert all(not torch.equal(lg[i], lg[j]) for i in range(16) for j in range(i))
     assert bool(torch.isfinite(lg).all())
+
+
+def test_input_pipeline_resize_bit_exact_vs_pil(golden_dir):
+    """N1 with the val transform's resize (dataloader_coco.py:288): uint8 frame -> PIL-bilinear resample -> ToTensor ->
+    Normalize -> zero-padded 1024^2 tile, on the GPU.  Integer work: bit-exact against (a) vectors PIL itself produced
+    (tests/golden/resize_pil.npz) and (b) the oracle's restatement on a full-size 3648 x 5472 frame (val.json's frame size,
+    resized to 512 x 768 as the reference would), then through the bit-exact normalise twin."""
+    from oracle import pil_resize as R
+    from wildlifemapper_amd.preprocess import tiles_from_u8, resized_size
+    fx = np.load(os.path.join(golden_dir, "resize_pil.npz"))
+    for i, (h, w, size, mx) in enumerate(fx["cases"]):
+        img, want_u8 = fx[f"in{i}"], fx[f"out{i}"]
+        oh, ow = want_u8.shape[:2]
+        assert resized_size(int(h), int(w), int(size), int(mx)) == (oh, ow)
+        got = tiles_from_u8(torch.from_numpy(img[None]).to(G.dev()), resize=(int(size), int(mx))).cpu().numpy()[0]
+        want = synth.normalize_tile(want_u8)
+        assert np.array_equal(got[:, :oh, :ow], want), i
+        assert not got[:, oh:, :].any() and not got[:, :, ow:].any()
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, (2, 3648, 5472, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:3648, 0:5472]
+    frame[1, ..., 0] = (yy // 16 + xx // 16) % 256                  # structured content in one channel
+    got = tiles_from_u8(torch.from_numpy(frame).to(G.dev()), resize=(768, 768)).cpu().numpy()
+    for b in range(2):
+        ref_u8 = R.val_transform_u8(frame[b], 768, 768)
+        assert ref_u8.shape == (512, 768, 3)
+        assert np.array_equal(got[b][:, :512, :768], synth.normalize_tile(ref_u8)), b
+        assert not got[b][:, 512:, :].any() and not got[b][:, :, 768:].any()
+    with pytest.raises(RuntimeError, match="canvas"):
+        tiles_from_u8(torch.zeros(1, 2000, 2000, 3, dtype=torch.uint8, device=G.dev()), resize=(1100, 0))

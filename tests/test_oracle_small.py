@@ -169,3 +169,21 @@ def test_oracle_end_to_end_vs_reference_fixture(golden_dir):
         assert rel(mine, ref) < 2e-5, (key, rel(mine, ref))
     det = O.detect(O.postprocess(out["pred_logits"], out["pred_boxes"], torch.tensor([[1024, 1024]]))[0])
     assert det["nms_index"].tolist() == fx["pp0_nms_index"].tolist()
+
+
+def test_pil_resize_restatement(golden_dir):
+    """oracle/pil_resize.py (the val transform's resize, dataloader_coco.py:288 -> PIL bilinear) against vectors PIL itself
+    produced (tests/golden/resize_pil.npz, oracle/gen_golden.py --only resize): bit-exact, and the output-size rule of
+    augmentation.py:80-99 on the dataset's frame sizes."""
+    from oracle import pil_resize as R
+    fx = np.load(os.path.join(golden_dir, "resize_pil.npz"))
+    for i, (h, w, size, mx) in enumerate(fx["cases"]):
+        img, want = fx[f"in{i}"], fx[f"out{i}"]
+        assert img.shape == (h, w, 3)
+        oh, ow = R.get_size_with_aspect_ratio((int(w), int(h)), int(size), int(mx))
+        assert want.shape == (oh, ow, 3)
+        assert np.array_equal(R.resize_bilinear_u8(img, oh, ow), want), i
+    assert R.get_size_with_aspect_ratio((5472, 3648), 768, 768) == (512, 768)      # coco_annotations/val.json frames
+    assert R.get_size_with_aspect_ratio((6000, 4000), 768, 768) == (512, 768)
+    assert R.get_size_with_aspect_ratio((3648, 5472), 768, 768) == (768, 512)
+    assert R.get_size_with_aspect_ratio((1000, 1000), 768, 768) == (768, 768)

@@ -46,6 +46,9 @@ SYMBOLS = {
     "wm_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_L), _I]),
     "wm_finalize_weights": (_I, [_P]),
     "wm_preprocess_u8": (_I, [_P, _P, _I, _I, _I, _P]),
+    "wm_preprocess_u8_resized": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm_resized_size": (_I, [_I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "wm_debug_resize_coeffs": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I), _I, C.POINTER(_I)]),
     "wm_hfc_fft": (_I, [_P, _P, _P, _I, _P]),
     "wm_encoder_forward": (_I, [_P, _P, _P, _P, _I, _P]),
     "wm_decoder_forward": (_I, [_P, _P, _P, _P, _I, _P]),

@@ -239,4 +239,69 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char*
     }
 }
 
+// ---------------------------------------------------------------------------
+// Input pipeline with the val transform's resize (dataloader_coco.py:286-292 -> augmentation.py:77-133
+// -> torchvision F.resize on a PIL image = PIL bilinear resample).  The arithmetic is Pillow's 8-bit ImagingResample:
+// separable antialiased triangle filter, 22-bit fixed-point coefficients (computed on the host in double exactly as
+// Resample.c does, wm_api.hip: resize_coeffs), horizontal pass into an 8-bit image, then the vertical pass, each output
+// clip8((sum + 2^21) >> 22) -- integer work, bit-exact with PIL.  The second kernel fuses the vertical pass with ToTensor,
+// Normalize and the zero padding to 1024 x 1024 (utils/misc.py:46-67).
+// ---------------------------------------------------------------------------
+constexpr int RESIZE_PREC_BITS = 22;
+
+// in [B,h,w,3] u8 -> tmp [B,h,ow,3] u8; bounds [ow][2] = (first input column, taps), kk [ow][ksize]
+__global__ __launch_bounds__(256) void resize_h_u8_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ tmp,
+                                                          const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                          int B, int h, int w, int ow) {
+    const int64_t total = (int64_t)B * h * ow;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int xx = (int)(i % ow);
+        const int64_t by = i / ow;                                   // b * h + y
+        const int x0 = bounds[2 * xx], n = bounds[2 * xx + 1];
+        const unsigned char* src = in + (by * w + x0) * 3;
+        const int* k = kk + (int64_t)xx * ksize;
+        int a0 = 1 << (RESIZE_PREC_BITS - 1), a1 = a0, a2 = a0;
+        for (int x = 0; x < n; ++x) {
+            const int c = k[x];
+            a0 += src[3 * x] * c; a1 += src[3 * x + 1] * c; a2 += src[3 * x + 2] * c;
+        }
+        unsigned char* dst = tmp + i * 3;
+        dst[0] = (unsigned char)min(max(a0 >> RESIZE_PREC_BITS, 0), 255);
+        dst[1] = (unsigned char)min(max(a1 >> RESIZE_PREC_BITS, 0), 255);
+        dst[2] = (unsigned char)min(max(a2 >> RESIZE_PREC_BITS, 0), 255);
+    }
+}
+
+// tmp [B,h,ow,3] u8 -> out [B,3,1024,1024] fp32: vertical pass to oh rows, /255, ImageNet normalise, zero canvas outside
+__global__ __launch_bounds__(256) void resize_v_normalize_kernel(const unsigned char* __restrict__ tmp, float* __restrict__ out,
+                                                                 const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                                 int B, int h, int ow, int oh) {
+#pragma clang fp contract(off)
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    const int64_t total = (int64_t)B * 1024 * 1024;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int xx = (int)(i & 1023), yy = (int)((i >> 10) & 1023);
+        const int64_t b = i >> 20;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (yy < oh && xx < ow) {
+            const int y0 = bounds[2 * yy], n = bounds[2 * yy + 1];
+            const unsigned char* src = tmp + ((b * h + y0) * (int64_t)ow + xx) * 3;
+            const int* k = kk + (int64_t)yy * ksize;
+            int a[3] = {1 << (RESIZE_PREC_BITS - 1), 1 << (RESIZE_PREC_BITS - 1), 1 << (RESIZE_PREC_BITS - 1)};
+            for (int y = 0; y < n; ++y) {
+                const int c = k[y];
+                const unsigned char* p = src + (int64_t)y * ow * 3;
+                a[0] += p[0] * c; a[1] += p[1] * c; a[2] += p[2] * c;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int u = min(max(a[c] >> RESIZE_PREC_BITS, 0), 255);
+                v[c] = ((float)u / 255.0f - mean[c]) / stdv[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[((b * 3 + c) * 1024 + yy) * (int64_t)1024 + xx] = v[c];
+    }
+}
+
 }  // namespace wm

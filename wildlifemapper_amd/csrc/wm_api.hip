@@ -13,6 +13,7 @@
 #include <set>
 #include <string>
 #include <algorithm>
+#include <array>
 #include <vector>
 
 #include "../../include/wm_hip.h"
@@ -1491,6 +1492,134 @@ extern "C" int wm_preprocess_u8(const uint8_t* img_dev, float* out_dev, int batc
         return fail("wm_preprocess_u8: batch %d, %dx%d outside 1..1024 (larger images are cropped by the caller, utils/misc.py:57-60)", batch, height, width);
     hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for((int64_t)batch * 1024 * 256)), dim3(256), 0, (hipStream_t)stream,
                        img_dev, out_dev, batch, height, width);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- N1: val transform resize (PIL bilinear semantics) + normalise + pad ----
+namespace {
+
+// augmentation.py:80-99 (get_size_with_aspect_ratio): (w, h), size, max_size -> (oh, ow)
+void resized_size(int w, int h, int size, int max_size, int* oh, int* ow) {
+    if (max_size > 0) {
+        const double mn = (double)std::min(w, h), mx = (double)std::max(w, h);       // Python floats are doubles
+        if (mx / mn * size > max_size) size = (int)std::nearbyint(max_size * mn / mx);               // Python round(): half to even
+    }
+    if ((w <= h && w == size) || (h <= w && h == size)) { *oh = h; *ow = w; return; }
+    if (w < h) { *ow = size; *oh = (int)((double)size * h / w); }
+    else { *oh = size; *ow = (int)((double)size * w / h); }
+}
+
+// Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc, bilinear filter (support 1), whole axis; double arithmetic
+// in the same operation order
+void resize_coeffs(int in_size, int out_size, std::vector<int>& bounds, std::vector<int>& kk, int& ksize) {
+    const double scale = (double)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 1.0 * filterscale;
+    ksize = (int)ceil(support) * 2 + 1;
+    bounds.assign((size_t)out_size * 2, 0);
+    kk.assign((size_t)out_size * ksize, 0);
+    const double ss = 1.0 / filterscale;
+    std::vector<double> w((size_t)ksize + 2);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < xmax; ++x) {
+            double v = (x + xmin - center + 0.5) * ss;
+            if (v < 0.0) v = -v;
+            const double wt = v < 1.0 ? 1.0 - v : 0.0;
+            w[x] = wt;
+            ww += wt;
+        }
+        for (int x = 0; x < xmax; ++x) {
+            if (ww != 0.0) w[x] /= ww;
+            kk[(size_t)xx * ksize + x] = w[x] < 0 ? (int)(-0.5 + w[x] * (1 << RESIZE_PREC_BITS)) : (int)(0.5 + w[x] * (1 << RESIZE_PREC_BITS));
+        }
+        bounds[(size_t)xx * 2] = xmin;
+        bounds[(size_t)xx * 2 + 1] = xmax;
+    }
+}
+
+struct ResizePlan {          // device tables of one geometry; owned by the library for the life of the process
+    int oh = 0, ow = 0, ksx = 0, ksy = 0;
+    int *bx = nullptr, *kx = nullptr, *by = nullptr, *ky = nullptr;
+};
+struct ResizeDevState {
+    std::map<std::array<int, 4>, ResizePlan> plans;      // (h, w, size, max_size)
+    unsigned char* tmp = nullptr;
+    size_t tmp_bytes = 0;
+};
+std::map<int, ResizeDevState> g_resize;
+
+int upload_ints(const std::vector<int>& v, int** out) {
+    HIP_TRY(hipMalloc((void**)out, v.size() * 4));
+    HIP_TRY(hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // namespace
+
+// host-only (tests): the coefficient tables the resize kernels use for one axis; ksize_out = taps per output, bounds [out][2], kk [out][ksize]
+extern "C" int wm_debug_resize_coeffs(int in_size, int out_size, int* bounds_out, int* kk_out, int kk_capacity, int* ksize_out) {
+    if (in_size <= 0 || out_size <= 0 || !bounds_out || !kk_out || !ksize_out) return fail("wm_debug_resize_coeffs: bad argument");
+    std::vector<int> b, k;
+    int ks = 0;
+    resize_coeffs(in_size, out_size, b, k, ks);
+    if ((size_t)kk_capacity < k.size()) return fail("wm_debug_resize_coeffs: need room for %zu coefficients", k.size());
+    memcpy(bounds_out, b.data(), b.size() * 4);
+    memcpy(kk_out, k.data(), k.size() * 4);
+    *ksize_out = ks;
+    return 0;
+}
+
+extern "C" int wm_resized_size(int height, int width, int size, int max_size, int* out_h, int* out_w) {
+    if (height <= 0 || width <= 0 || size <= 0 || !out_h || !out_w) return fail("wm_resized_size: bad argument");
+    resized_size(width, height, size, max_size, out_h, out_w);
+    return 0;
+}
+
+extern "C" int wm_preprocess_u8_resized(const uint8_t* img_dev, float* out_dev, int batch, int height, int width, int size, int max_size,
+                                        void* stream) {
+    if (!img_dev || !out_dev) return fail("wm_preprocess_u8_resized: null buffer");
+    if (batch <= 0 || height <= 0 || width <= 0 || size <= 0) return fail("wm_preprocess_u8_resized: batch %d, %dx%d, size %d", batch, height, width, size);
+    int oh, ow;
+    resized_size(width, height, size, max_size, &oh, &ow);
+    if (oh > 1024 || ow > 1024 || oh <= 0 || ow <= 0)
+        return fail("wm_preprocess_u8_resized: %dx%d resizes to %dx%d, outside the 1024x1024 canvas (utils/misc.py:57-60 crops; not built)", height, width, oh, ow);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    ResizeDevState& st = g_resize[dev];
+    const std::array<int, 4> key{height, width, size, max_size};
+    auto it = st.plans.find(key);
+    if (it == st.plans.end()) {
+        ResizePlan pl;
+        pl.oh = oh; pl.ow = ow;
+        std::vector<int> b, k;
+        resize_coeffs(width, ow, b, k, pl.ksx);
+        WM_TRY(upload_ints(b, &pl.bx)); WM_TRY(upload_ints(k, &pl.kx));
+        resize_coeffs(height, oh, b, k, pl.ksy);
+        WM_TRY(upload_ints(b, &pl.by)); WM_TRY(upload_ints(k, &pl.ky));
+        it = st.plans.emplace(key, pl).first;
+    }
+    const ResizePlan& pl = it->second;
+    const size_t need = (size_t)batch * height * ow * 3;
+    if (need > st.tmp_bytes) {
+        if (st.tmp) HIP_TRY(hipFree(st.tmp));
+        st.tmp = nullptr; st.tmp_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&st.tmp, need));
+        st.tmp_bytes = need;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(resize_h_u8_kernel, dim3(grid_for((int64_t)batch * height * ow)), dim3(256), 0, s, img_dev, st.tmp, (const int*)pl.bx,
+                       (const int*)pl.kx, pl.ksx, batch, height, width, ow);
+    hipLaunchKernelGGL(resize_v_normalize_kernel, dim3(grid_for((int64_t)batch * 1024 * 1024)), dim3(256), 0, s, (const unsigned char*)st.tmp, out_dev,
+                       (const int*)pl.by, (const int*)pl.ky, pl.ksy, batch, height, ow, oh);
     HIP_TRY(hipGetLastError());
     return 0;
 }
