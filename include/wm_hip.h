@@ -83,6 +83,7 @@ typedef struct wm_box_record {
 #define WM_FLAG_CONF 1
 #define WM_FLAG_SCORE 2
 #define WM_FLAG_NMS 4
+#define WM_FLAG_MERGED 8   /* wm_merge_tiles_nms: survives the cross-tile NMS of one frame */
 
 const char* wm_last_error(void);
 int wm_abi_version(void);
@@ -150,6 +151,18 @@ int wm_postprocess_nms(wm_handle* h, const float* logits_dev, const float* boxes
 int wm_forward(wm_handle* h, const float* x_dev, const float* target_sizes_dev,
                float* logits_dev, float* boxes_dev, wm_box_record* records_dev,
                int batch, void* stream);
+
+/* ---- large-frame front end (no reference behaviour: the reference down-scales whole frames) -------
+ * wm_tile_frame_u8: cut n tiles of 1024 x 1024 at origins[n][2] = (y0, x0) (int32, device) out of ONE uint8 HWC frame
+ * [H,W,3] into the model input [n,3,1024,1024] fp32 (ToTensor + Normalize; zeros where a tile reaches past the frame).
+ * wm_merge_tiles_nms: records [n_tiles * WM_NUM_QUERIES] of those tiles (wm_forward / wm_postprocess_nms output, boxes
+ * in tile pixels) -> merged records in frame coordinates: slots that survived their tile's NMS compete in one more
+ * greedy class-agnostic NMS (IoU > iou_thr suppresses, descending score, stable), survivors carry WM_FLAG_MERGED and
+ * nms_rank = their position in the merged list.  n_tiles * WM_NUM_QUERIES <= 4096. */
+int wm_tile_frame_u8(const uint8_t* frame_dev, const int32_t* origins_dev, float* out_dev, int n_tiles, int height, int width,
+                     void* stream);
+int wm_merge_tiles_nms(const wm_box_record* records_dev, const int32_t* origins_dev, int n_tiles, float iou_thr,
+                       wm_box_record* merged_dev, void* stream);
 
 /* ---- intermediate taps (parity tests) -------------------------------------
  * Copies the fp32 token stream (B,64,64,embed_dim) as it stood after the patch embed + pos_embed

@@ -17,7 +17,7 @@ NUM_QUERIES, NUM_LOGITS = 51, 8
 KCLASS_NAMES = ("gemm16", "attn_window", "attn_global", "layernorm", "other")
 GEMM_VARIANTS = ("v1_128", "v2_160", "v2_128", "v3_lockstep", "v3_conv3x3", "v5_320", "v5_320_res", "v5_256", "v5_256_res",
                  "v5_320_lnf", "v5_256_lnf", "fp8_320", "fp8_256")
-FLAG_CONF, FLAG_SCORE, FLAG_NMS = 1, 2, 4
+FLAG_CONF, FLAG_SCORE, FLAG_NMS, FLAG_MERGED = 1, 2, 4, 8
 CFG_FUSE_LN = 1
 
 
@@ -49,6 +49,8 @@ SYMBOLS = {
     "wm_preprocess_u8_resized": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "wm_resized_size": (_I, [_I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
     "wm_debug_resize_coeffs": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I), _I, C.POINTER(_I)]),
+    "wm_tile_frame_u8": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "wm_merge_tiles_nms": (_I, [_P, _P, _I, _F, _P, _P]),
     "wm_hfc_fft": (_I, [_P, _P, _P, _I, _P]),
     "wm_encoder_forward": (_I, [_P, _P, _P, _P, _I, _P]),
     "wm_decoder_forward": (_I, [_P, _P, _P, _P, _I, _P]),

@@ -228,4 +228,136 @@ __global__ __launch_bounds__(64) void postprocess_nms_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------
+// Large-frame front end: merge the detections of overlapping 1024 x 1024 tiles of one frame.
+// Input: the per-tile records of postprocess_nms_kernel (boxes in tile pixels) and each tile's origin in the frame.
+// Candidates = slots that survived their own tile's NMS; their boxes move to frame coordinates and one more greedy
+// class-agnostic NMS (the same arithmetic, un-contracted) runs over all of them: an animal seen by two overlapping tiles
+// is reported once.  One workgroup of 1024 threads, up to 4096 slots (80 tiles); candidates are ranked by descending
+// score, ties by ascending slot (stable).  Output records: frame-coordinate boxes, WM_FLAG_MERGED set on survivors,
+// nms_rank = position in the merged list (-1 otherwise).  No reference behaviour exists for this step (the reference
+// down-scales whole frames, dataloader_coco.py:288); the checker is the numpy restatement in oracle/tiling_oracle.py.
+// ---------------------------------------------------------------------------
+constexpr int MERGE_MAX_SLOTS = 4096, MERGE_THREADS = 1024, MERGE_PER = MERGE_MAX_SLOTS / MERGE_THREADS;
+
+__global__ __launch_bounds__(1024) void merge_tiles_nms_kernel(const wm_box_record* __restrict__ rec, const int* __restrict__ origins,
+                                                               int n_slots, float iou_thr, wm_box_record* __restrict__ out) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sx0 = (float*)smem;                 // [MERGE_MAX_SLOTS] each
+    float* sy0 = sx0 + MERGE_MAX_SLOTS;
+    float* sx1 = sy0 + MERGE_MAX_SLOTS;
+    float* sy1 = sx1 + MERGE_MAX_SLOTS;
+    float* sscore = sy1 + MERGE_MAX_SLOTS;
+    int* sorder = (int*)(sscore + MERGE_MAX_SLOTS);
+    unsigned char* scand = (unsigned char*)(sorder + MERGE_MAX_SLOTS);
+    unsigned char* sdead = scand + MERGE_MAX_SLOTS;
+    int& s_ncand = *(int*)(sdead + MERGE_MAX_SLOTS);           // everything in the dynamic region (16-byte aligned base)
+    const int tid = threadIdx.x;
+    wm_box_record r[MERGE_PER];
+    bool cand[MERGE_PER];
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MERGE_PER; ++k) {
+        const int i = tid + k * MERGE_THREADS;
+        cand[k] = false;
+        if (i < n_slots) {
+            r[k] = rec[i];
+            const int tile = i / WM_NUM_QUERIES;
+            const float oy = (float)origins[2 * tile], ox = (float)origins[2 * tile + 1];
+            r[k].box[0] += ox; r[k].box[1] += oy; r[k].box[2] += ox; r[k].box[3] += oy;
+            cand[k] = (r[k].flags & WM_FLAG_NMS) != 0;
+            sx0[i] = r[k].box[0]; sy0[i] = r[k].box[1]; sx1[i] = r[k].box[2]; sy1[i] = r[k].box[3];
+            sscore[i] = r[k].score;
+            scand[i] = cand[k] ? 1 : 0;
+            sdead[i] = 0;
+            if (cand[k]) atomicAdd(&s_ncand, 1);
+        }
+    }
+    __syncthreads();
+    const int ncand = s_ncand;
+    int rank[MERGE_PER];
+#pragma unroll
+    for (int k = 0; k < MERGE_PER; ++k) {
+        const int i = tid + k * MERGE_THREADS;
+        rank[k] = 0;
+        if (cand[k]) {
+            const float sc = r[k].score;
+            int rk = 0;
+            for (int j = 0; j < n_slots; ++j)
+                if (scand[j] && (sscore[j] > sc || (sscore[j] == sc && j < i))) ++rk;
+            rank[k] = rk;
+            sorder[rk] = i;
+        }
+    }
+    __syncthreads();
+    int merged_rank[MERGE_PER];
+#pragma unroll
+    for (int k = 0; k < MERGE_PER; ++k) merged_rank[k] = -1;
+    int kept = 0;
+    for (int rr = 0; rr < ncand; ++rr) {
+        const int a = sorder[rr];
+        const bool alive = sdead[a] == 0;            // uniform across the workgroup
+        if (alive) {
+            const float ax0 = sx0[a], ay0 = sy0[a], ax1 = sx1[a], ay1 = sy1[a];
+            const float aarea = (ax1 - ax0) * (ay1 - ay0);
+#pragma unroll
+            for (int k = 0; k < MERGE_PER; ++k) {
+                const int i = tid + k * MERGE_THREADS;
+                if (i == a) merged_rank[k] = kept;
+                if (cand[k] && rank[k] > rr && sdead[i] == 0) {
+                    const float xx0 = fmaxf(ax0, r[k].box[0]), yy0 = fmaxf(ay0, r[k].box[1]);
+                    const float xx1 = fminf(ax1, r[k].box[2]), yy1 = fminf(ay1, r[k].box[3]);
+                    const float iw = fmaxf(0.f, xx1 - xx0), ih = fmaxf(0.f, yy1 - yy0);
+                    const float inter = iw * ih;
+                    const float area = (r[k].box[2] - r[k].box[0]) * (r[k].box[3] - r[k].box[1]);
+                    const float iou = inter / (aarea + area - inter);
+                    if (iou > iou_thr) sdead[i] = 1;
+                }
+            }
+            ++kept;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < MERGE_PER; ++k) {
+        const int i = tid + k * MERGE_THREADS;
+        if (i < n_slots) {
+            r[k].flags = (r[k].flags & ~WM_FLAG_MERGED) | (merged_rank[k] >= 0 ? WM_FLAG_MERGED : 0);
+            r[k].nms_rank = merged_rank[k];
+            out[i] = r[k];
+        }
+    }
+}
+
+// Cut 1024 x 1024 tiles at `origins` (y0, x0) out of one uint8 HWC frame [H,W,3] into the model's input tensor
+// [n,3,1024,1024] fp32: ToTensor + Normalize as preprocess_u8_kernel, zeros where a tile reaches past the frame.
+__global__ __launch_bounds__(256) void tile_frame_u8_kernel(const unsigned char* __restrict__ frame, const int* __restrict__ origins,
+                                                            float* __restrict__ out, int n, int H, int W) {
+#pragma clang fp contract(off)
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    const int64_t total = (int64_t)n * 1024 * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x4 = (int)(i & 255) * 4;
+        const int y = (int)((i >> 8) & 1023);
+        const int64_t t = i >> 18;
+        const int fy = origins[2 * t] + y, fx0 = origins[2 * t + 1] + x4;
+        f32x4 v[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (fy >= 0 && fy < H) {
+            const unsigned char* row = frame + (int64_t)fy * W * 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int fx = fx0 + j;
+                if (fx >= 0 && fx < W) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c][j] = ((float)row[(int64_t)fx * 3 + c] / 255.0f - mean[c]) / stdv[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *(f32x4*)(out + ((t * 3 + c) * 1024 + y) * (int64_t)1024 + x4) = v[c];
+    }
+}
+
 }  // namespace wm

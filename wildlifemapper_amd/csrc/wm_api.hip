@@ -1496,6 +1496,30 @@ extern "C" int wm_preprocess_u8(const uint8_t* img_dev, float* out_dev, int batc
     return 0;
 }
 
+// ---- N3: large-frame tiling front end ----
+extern "C" int wm_tile_frame_u8(const uint8_t* frame_dev, const int32_t* origins_dev, float* out_dev, int n_tiles, int height, int width,
+                                void* stream) {
+    if (!frame_dev || !origins_dev || !out_dev) return fail("wm_tile_frame_u8: null buffer");
+    if (n_tiles <= 0 || height <= 0 || width <= 0) return fail("wm_tile_frame_u8: n_tiles %d, frame %dx%d", n_tiles, height, width);
+    hipLaunchKernelGGL(tile_frame_u8_kernel, dim3(grid_for((int64_t)n_tiles * 1024 * 256)), dim3(256), 0, (hipStream_t)stream, frame_dev,
+                       (const int*)origins_dev, out_dev, n_tiles, height, width);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wm_merge_tiles_nms(const wm_box_record* records_dev, const int32_t* origins_dev, int n_tiles, float iou_thr,
+                                  wm_box_record* merged_dev, void* stream) {
+    if (!records_dev || !origins_dev || !merged_dev) return fail("wm_merge_tiles_nms: null buffer");
+    const int n_slots = n_tiles * WM_NUM_QUERIES;
+    if (n_tiles <= 0 || n_slots > MERGE_MAX_SLOTS) return fail("wm_merge_tiles_nms: %d tiles (1..%d)", n_tiles, MERGE_MAX_SLOTS / WM_NUM_QUERIES);
+    constexpr int LDS = MERGE_MAX_SLOTS * (5 * 4 + 4 + 2) + 16;
+    WM_TRY(set_max_lds((const void*)merge_tiles_nms_kernel, LDS));
+    hipLaunchKernelGGL(merge_tiles_nms_kernel, dim3(1), dim3(MERGE_THREADS), LDS, (hipStream_t)stream, records_dev, (const int*)origins_dev, n_slots,
+                       iou_thr, merged_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ---- N1: val transform resize (PIL bilinear semantics) + normalise + pad ----
 namespace {
 
