@@ -472,6 +472,25 @@ def test_gemm8_16bit_and_fp8_outputs(M, N, K, act):
     assert G.rel_l2(got, y) < 0.04
 
 
+def test_gemm8_k64_variant_matches_default(monkeypatch):
+    """The 64-byte-K-step variant (4-slot ring, DMA pieces between the MFMAs; WM_GEMM8_BK=64) computes the same bits as
+    the default 128-byte one: both accumulate the 64-deep MFMA steps in the same order."""
+    dev = G.dev()
+    M, N, K = 1024, 768, 1280
+    a8 = G.to_fp8(torch.randn(M, K, device=dev))
+    w8, sc = G.quant_weight_fp8(torch.randn(N, K, device=dev) / math.sqrt(K))
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev)
+    outs = {}
+    for bk in ("128", "64"):
+        monkeypatch.setenv("WM_GEMM8_BK", bk)
+        outs[bk] = (G.gemm8(a8, w8, sc, bias, res, 0, "f32"), G.gemm8(a8, w8, sc, bias, None, 1, "8"), G.gemm8(a8, w8, sc, bias, None, 0, "16"))
+    for x, y in zip(outs["128"], outs["64"]):
+        assert torch.equal(x, y)
+    want = res + (G.from_fp8(a8) @ G.from_fp8(w8).t()) * sc + bias
+    assert G.rel_l2(outs["64"][0], want) < 1e-5
+
+
 def test_gemm8_rejects_bad_shapes():
     dev = G.dev()
     a8 = torch.zeros(256, 128, device=dev, dtype=torch.uint8)

@@ -37,6 +37,7 @@ struct AttnArgs {
     const float* rel_h; const float* rel_w;         // [2*S-1, HD] fp32 or null
     const float* qkv_bias;                          // window kernel: [3*D] fp32 (padded tokens)
     int heads;
+    unsigned char* out8;                            // WM_PREC_FP8: write the output as e4m3 bytes (row stride out_stride bytes) instead of 16-bit
 };
 
 template <int HD> struct AttnGeom {
@@ -181,7 +182,7 @@ __device__ __forceinline__ void v_pad_ones(char* sV, int rows, int tid, int nthr
 
 // Normalise and store O^T: lane (c = lane&31, h) holds dims 32dt + (r&3) + 8(r>>2) + 4h of query c.
 template <class T, int HD>
-__device__ __forceinline__ void store_out(SoftmaxState<AttnGeom<HD>::NDT>& st, u16* out_row, int lane, bool valid) {
+__device__ __forceinline__ void store_out(SoftmaxState<AttnGeom<HD>::NDT>& st, u16* out_row, int lane, bool valid, unsigned char* out8_row = nullptr) {
     using G = AttnGeom<HD>;
     const int h = lane >> 5;
     float l;
@@ -195,10 +196,15 @@ __device__ __forceinline__ void store_out(SoftmaxState<AttnGeom<HD>::NDT>& st, u
         for (int rg = 0; rg < 4; ++rg) {
             const int d = 32 * dt + 8 * rg + 4 * h;
             if (d < HD) {
-                typename T::vec4 o;
+                if (out8_row) {                              // wave-uniform: e4m3 A operand of the fp8 proj GEMM (gemm8.h)
+                    const f32x4 v{st.o[dt][4 * rg] * inv, st.o[dt][4 * rg + 1] * inv, st.o[dt][4 * rg + 2] * inv, st.o[dt][4 * rg + 3] * inv};
+                    *(unsigned*)(out8_row + d) = pack4_e4m3(v);
+                } else {
+                    typename T::vec4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = T::from_f32(st.o[dt][4 * rg + j] * inv);
-                *(typename T::vec4*)(out_row + d) = o;
+                    for (int j = 0; j < 4; ++j) o[j] = T::from_f32(st.o[dt][4 * rg + j] * inv);
+                    *(typename T::vec4*)(out_row + d) = o;
+                }
             }
         }
 }
@@ -396,7 +402,8 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
         __syncthreads();
     }
     u16* orow = p.out + ((size_t)b * p.nq + q0 + c) * p.out_stride + head * HD;
-    store_out<T, HD>(st, orow, lane, true);
+    unsigned char* orow8 = p.out8 ? p.out8 + ((size_t)b * p.nq + q0 + c) * p.out_stride + head * HD : nullptr;
+    store_out<T, HD>(st, orow, lane, true, orow8);
 }
 
 // ---------------------------------------------------------------------------
@@ -602,7 +609,8 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
             decode(item, b, win, head);
             const QInfo qo = q_info(item);
             u16* orow = p.out + qo.row * p.out_stride + head * HD;
-            store_out<T, HD>(st, orow, lane, qo.valid);
+            unsigned char* orow8 = p.out8 ? p.out8 + qo.row * p.out_stride + head * HD : nullptr;
+            store_out<T, HD>(st, orow, lane, qo.valid, orow8);
         }
         if (!has_next) break;
         __syncthreads();                                  // every wave is done with this item's K / V

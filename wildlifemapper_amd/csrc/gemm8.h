@@ -38,20 +38,31 @@ struct Gemm8Args {
     u16* out16;                   // [M][N] 16-bit (type T) or null
     unsigned char* out8;          // [M][N] e4m3 or null
     int M, N, K, act;
+    unsigned long long* dbg;      // DBG instance only: [grid][4] stamps
 };
 
-struct G8 {
-    static constexpr int BM = 256, BN = 256, BKB = 128, NSLOT = 2;
+// BKB = bytes (= fp8 elements) of K per LDS step: 128 (two MFMAs deep, 2 slots of 64 KiB, DMA issued after X_s) or
+// 64 (one MFMA deep, 4 slots of 32 KiB, three K-steps of DMA in flight, each wave's pieces issued between the MFMAs of its
+// own MFMA interval).  Measured (tools/gemm8_bench.py, B = 16): see DESIGN.md section 5.
+template <int BKB_> struct G8 {
+    static constexpr int BM = 256, BN = 256, BKB = BKB_, NSLOT = BKB_ == 128 ? 2 : 4;
     static constexpr int A_BYTES = BM * BKB, W_BYTES = BN * BKB, STAGE = A_BYTES + W_BYTES;
     static constexpr int LDS = NSLOT * STAGE + 32 * 1024;          // ring + epilogue room (second residual landing buffer)
     static constexpr int MT = 4, NT = 2, KS = BKB / 64;
-    static constexpr int P = (BM / 8 + BN / 8) / 8;                // DMA pieces per wave and K-step
+    static constexpr int PROWS = 1024 / BKB;                       // rows per 1-KiB DMA piece
+    static constexpr int PW = (BM / PROWS) / 8;                    // A (and W) pieces per wave and K-step
+    static constexpr int AHEAD = NSLOT - 1;
 };
+constexpr int G8_BM = 256, G8_BN = 256;
 
-template <class T>
+// DBG (dev, WM_GEMM8_DBG=1): every workgroup records wall-clock stamps (entry, first barrier passed, loop end, stores
+// acknowledged) into p.dbg; a separate instance, the product kernel carries none of it.
+template <class T, int BKB, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(Gemm8Args p) {
-    using C = G8;
+    using C = G8<BKB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long wt0 = 0, wt1 = 0, wt2 = 0, mt1 = 0, mt2 = 0;
+    if constexpr (DBG) wt0 = wall_clock64();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -73,31 +84,33 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(Gemm8Args p) {
         n0 = (in_group / gsz) * C::BN;
     }
 
-    // DMA piece = 8 rows x 128 B; lane -> row (lane >> 3), physical chunk (lane & 7); the row's swizzle key is
-    // ((row >> 1) & 7) = (4 (piece & 1) + (lane >> 4)) & 7, so even and odd pieces have their own per-lane source offset
+    // DMA piece = 1 KiB = PROWS rows of BKB bytes; lane -> row, physical 16-byte chunk.  Swizzle key of a row:
+    //   BKB 128: (row >> 1) & 7 = (4 (piece & 1) + (lane >> 4)) & 7: even and odd pieces have their own per-lane source offset
+    //   BKB  64: (row >> 2) & 3 = (lane >> 4) & 3, the same for every piece
     const size_t row_bytes = (size_t)K;
     unsigned lane_off[2];
 #pragma unroll
-    for (int par = 0; par < 2; ++par)
-        lane_off[par] = (unsigned)(lane >> 3) * (unsigned)K + (unsigned)((((lane & 7) ^ ((4 * par + (lane >> 4)) & 7))) << 4);
+    for (int par = 0; par < 2; ++par) {
+        if constexpr (BKB == 128) lane_off[par] = (unsigned)(lane >> 3) * (unsigned)K + (unsigned)((((lane & 7) ^ ((4 * par + (lane >> 4)) & 7))) << 4);
+        else lane_off[par] = (unsigned)(lane >> 2) * (unsigned)K + (unsigned)((((lane & 3) ^ ((lane >> 4) & 3))) << 4);
+    }
+    const char* a_wave = Ab + (size_t)(m0 + wave * 32) * row_bytes;             // this wave's A pieces: rows 32 wave .. + 31
+    const char* w_wave = Wb + (size_t)(n0 + wave * 32) * row_bytes;
+    auto piece_dma = [&](int slot, int s, int i) {                              // i < PW: A pieces, else W pieces
+        const int j = i < C::PW ? i : i - C::PW;
+        const char* base = (i < C::PW ? a_wave : w_wave) + (size_t)(j * C::PROWS) * row_bytes + (size_t)s * C::BKB;
+        __builtin_amdgcn_global_load_lds(base + lane_off[j & 1],
+                                         WM_LDS_PTR(smem + slot * C::STAGE + (i < C::PW ? 0 : C::A_BYTES) + (wave * C::PW + j) * 1024), 16, 0, 0);
+    };
     auto stage = [&](int slot, int s) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave * 4 + i;
-            const char* base = Ab + (size_t)(m0 + piece * 8) * row_bytes + (size_t)s * C::BKB;
-            __builtin_amdgcn_global_load_lds(base + lane_off[i & 1], WM_LDS_PTR(smem + slot * C::STAGE + piece * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave * 4 + i;
-            const char* base = Wb + (size_t)(n0 + piece * 8) * row_bytes + (size_t)s * C::BKB;
-            __builtin_amdgcn_global_load_lds(base + lane_off[i & 1], WM_LDS_PTR(smem + slot * C::STAGE + C::A_BYTES + piece * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < 2 * C::PW; ++i) piece_dma(slot, s, i);
     };
 
-    // fragment read: row r32 of a 32-row tile, chunks 4 ks + 2 h and + 1 -> two ds_read_b128 whose addresses differ by
-    // XOR constants only (the swizzle key has no bit in common with them)
-    const int frag_off = r32 * C::BKB + ((((2 * h) ^ ((r32 >> 1) & 7))) << 4);
+    // fragment read: row r32 of a 32-row tile, 32 bytes = chunks c, c + 1 -> two ds_read_b128 whose addresses differ by XOR
+    // constants only (the swizzle key has no bit in common with them)
+    const int key = BKB == 128 ? ((r32 >> 1) & 7) : ((r32 >> 2) & 3);
+    const int frag_off = r32 * C::BKB + ((((2 * h) ^ key)) << 4);
     const int rd_a = (wr * 128) * C::BKB + frag_off;
     const int rd_w = C::A_BYTES + (wc * 64) * C::BKB + frag_off;
 
@@ -125,51 +138,182 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(Gemm8Args p) {
         }
     };
     const int one = 0x7f7f7f7f;                              // E8M0 127 = 2^0 for every 32-element block
-    auto mfmas = [&]() {
+    // the MFMAs of one K-step; DMA: this wave's pieces of step `s` between the first of them (one piece per 64-cycle MFMA:
+    // its issue hides behind the matrix pipe instead of lengthening the load interval)
+    auto mfmas = [&](int slot, int s, auto dma_tag) {
+        constexpr bool DMA = decltype(dma_tag)::value;
+        int idx = 0;
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
             for (int mi = 0; mi < C::MT; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < C::NT; ++ni)
+                for (int ni = 0; ni < C::NT; ++ni) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0, one, 0, one);
+                    if constexpr (DMA) {
+                        if (idx < 2 * C::PW) piece_dma(slot, s, idx);
+                    }
+                    ++idx;
+                }
+        if constexpr (DMA) {
+#pragma unroll
+            for (int i = 0; i < 2 * C::PW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, C::KS * C::MT * C::NT - 2 * C::PW, 0);
+        }
     };
     auto barrier = [&]() {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    using NO = std::false_type;
+    using YES = std::true_type;
+    // DBG: waves 0 and 4 of workgroup 0 record s_memtime at 6 points of K-steps 4..7 (lane = (step - 4) * 6 + point)
+    unsigned tmark = 0;
+    auto mark = [&](int s, int k) {
+        if constexpr (DBG) {
+            const unsigned t = (unsigned)__builtin_readcyclecounter();
+            const int idx = (s - 4) * 6 + k;
+            tmark = (lane == idx) ? t : tmark;
+        }
+    };
 
-    // ---- main loop: two slots, one K-step of DMA in flight.  Both wave groups issue the pieces of step s + 1 right after
-    // X_s: slot (s + 1) & 1 was last read for step s - 1, by waves 0-3 before Y_(s-1) and by waves 4-7 between Y_(s-1) and
-    // X_s (drained with lgkmcnt(0) before they arrive at X_s).  A wave waits for its own pieces of step s (vmcnt(0): nothing
-    // younger is outstanding at that point) before X_s, and every read of slot s & 1 follows X_s.
-    stage(0, 0);
-    if (wr == 0) {
+    if constexpr (BKB == 128) {
+        // ---- two slots, one K-step of DMA in flight.  Both wave groups issue the pieces of step s + 1 right after X_s: slot
+        // (s + 1) & 1 was last read for step s - 1, by waves 0-3 before Y_(s-1) and by waves 4-7 between Y_(s-1) and X_s
+        // (drained with lgkmcnt(0) before they arrive at X_s).  A wave waits for its own pieces of step s (vmcnt(0): nothing
+        // younger is outstanding at that point) before X_s, and every read of slot s & 1 follows X_s.  (Placing the pieces in
+        // each group's own load interval as gemm16_v5.h does measured 3-7 % slower; between the MFMAs needs more than the
+        // 256 registers: 128 accumulators + 96 operand registers leave no room for the address temporaries.)
+        stage(0, 0);
+        if (wr == 0) {
 #pragma unroll 1
-        for (int s = 0; s < ns; ++s) {
-            wait_vmcnt<0>();
-            barrier();                                      // X_s
-            if (s + 1 < ns) stage((s + 1) & 1, s + 1);
-            read_frags(s & 1);
-            barrier();                                      // Y_s
-            mfmas();
+            for (int s = 0; s < ns; ++s) {
+                wait_vmcnt<0>();
+                barrier();                                  // X_s
+                if constexpr (DBG) { if (s == 0) { wt1 = wall_clock64(); mt1 = __builtin_readcyclecounter(); } }
+                if (s + 1 < ns) stage((s + 1) & 1, s + 1);
+                read_frags(s & 1);
+                barrier();                                  // Y_s
+                mfmas(0, 0, NO{});
+            }
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < ns; ++s) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of the slot about to be overwritten are back
+                wait_vmcnt<0>();
+                barrier();                                  // X_s
+                if (s + 1 < ns) stage((s + 1) & 1, s + 1);
+                if (s > 0) mfmas(0, 0, NO{});               // step s - 1
+                barrier();                                  // Y_s
+                read_frags(s & 1);
+            }
+            mfmas(0, 0, NO{});                              // step ns - 1
         }
     } else {
+        // ---- NSLOT slots, AHEAD = NSLOT - 1 K-steps of DMA in flight.  During step s a wave issues its pieces of step s + AHEAD
+        // into slot (s - 1) % NSLOT, between the MFMAs of its MFMA interval (waves 0-3: after Y_s; waves 4-7: after X_s).  That
+        // slot was last read for step s - 1: by waves 0-3 before Y_(s-1), by waves 4-7 between Y_(s-1) and X_s (drained with
+        // lgkmcnt(0) before X_s), so every issue follows the last read.  A wave waits for its own pieces of step s -- all but
+        // the (AHEAD - 1) younger steps' pieces -- before X_s; every read of slot s % NSLOT follows X_s.
+        constexpr int PWS = 2 * C::PW;                      // pieces per wave and step
+        static_assert(C::AHEAD == 3, "wait ladder below is written for three steps in flight");
+        auto wait_tail = [&](int s) {                       // last AHEAD steps: fewer younger pieces outstanding
+            if (s + 2 < ns) wait_vmcnt<2 * PWS>();
+            else if (s + 1 < ns) wait_vmcnt<PWS>();
+            else wait_vmcnt<0>();
+        };
+#pragma unroll
+        for (int i = 0; i < C::AHEAD; ++i) stage(i, i);     // ns > AHEAD (K >= 256)
+        int slot = 0;                                       // slot of step s
+        auto prev = [](int v) { return v == 0 ? C::NSLOT - 1 : v - 1; };
+        auto next = [](int v) { return v == C::NSLOT - 1 ? 0 : v + 1; };
+        const int n_main = ns - C::AHEAD;                   // steps that still have a step s + AHEAD to request
+        // (the loops are peeled so that each has ONE MFMA block: with / without the DMA pieces between the MFMAs)
+        if (wr == 0) {
 #pragma unroll 1
-        for (int s = 0; s < ns; ++s) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of the slot about to be overwritten are back
-            wait_vmcnt<0>();
-            barrier();                                      // X_s
-            if (s + 1 < ns) stage((s + 1) & 1, s + 1);
-            if (s > 0) mfmas();                             // step s - 1
-            barrier();                                      // Y_s
-            read_frags(s & 1);
+            for (int s = 0; s < n_main; ++s) {
+                mark(s, 0);
+                wait_vmcnt<2 * PWS>();
+                mark(s, 1);
+                barrier();                                  // X_s
+                if constexpr (DBG) { if (s == 0) { wt1 = wall_clock64(); mt1 = __builtin_readcyclecounter(); } }
+                mark(s, 2);
+                read_frags(slot);
+                mark(s, 3);
+                barrier();                                  // Y_s
+                mark(s, 4);
+                mfmas(prev(slot), s + C::AHEAD, YES{});
+                mark(s, 5);
+                slot = next(slot);
+            }
+#pragma unroll 1
+            for (int s = n_main; s < ns; ++s) {
+                wait_tail(s);
+                barrier();                                  // X_s
+                read_frags(slot);
+                barrier();                                  // Y_s
+                mfmas(0, 0, NO{});
+                slot = next(slot);
+            }
+        } else {
+            {                                               // s = 0: nothing to multiply yet
+                wait_vmcnt<2 * PWS>();
+                barrier();                                  // X_0
+                stage(prev(slot), C::AHEAD);
+                barrier();                                  // Y_0
+                read_frags(slot);
+                slot = next(slot);
+            }
+#pragma unroll 1
+            for (int s = 1; s < n_main; ++s) {
+                mark(s, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_vmcnt<2 * PWS>();
+                mark(s, 1);
+                barrier();                                  // X_s
+                mark(s, 2);
+                mfmas(prev(slot), s + C::AHEAD, YES{});      // MFMAs of step s - 1
+                mark(s, 3);
+                barrier();                                  // Y_s
+                mark(s, 4);
+                read_frags(slot);
+                mark(s, 5);
+                slot = next(slot);
+            }
+#pragma unroll 1
+            for (int s = n_main > 1 ? n_main : 1; s < ns; ++s) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_tail(s);
+                barrier();                                  // X_s
+                mfmas(0, 0, NO{});                          // MFMAs of step s - 1
+                barrier();                                  // Y_s
+                read_frags(slot);
+                slot = next(slot);
+            }
+            mfmas(0, 0, NO{});                              // step ns - 1
         }
-        mfmas();                                            // step ns - 1
     }
 
+    if constexpr (DBG) {
+        wt2 = wall_clock64(); mt2 = __builtin_readcyclecounter();
+        if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane < 24) ((unsigned*)(p.dbg + (size_t)gridDim.x * 4 + 2))[wr * 24 + lane] = tmark;
+    }
     // ---- epilogue (through LDS so that every global access is row-contiguous; see gemm16_v5.h) ----
     // lane holds, per 32 x 32 tile (mi, ni): row m = r32, columns n = 8 g + 4 h + (0..3) for g = 0..3 (registers 4 g .. 4 g + 3)
+    // per-channel weight scales and biases of this lane's 8 column groups: requested before the barrier, so their round
+    // trip overlaps the last MFMAs draining
+    f32x4 scv[C::NT][4], biv[C::NT][4];
+#pragma unroll
+    for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = 64 * wc + 32 * ni + 8 * g + 4 * h;
+            scv[ni][g] = *(const f32x4*)(p.wscale + n0 + nl);
+            biv[ni][g] = p.bias ? *(const f32x4*)(p.bias + n0 + nl) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0)
     barrier();                                              // every wave is done with the ring
     auto scaled = [&](int mi, int ni, int g, const f32x4& sc, const f32x4& bi) {
@@ -202,12 +346,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(Gemm8Args p) {
             const int mi = q >> 1, ni = q & 1;
             if (q + 1 < 8) res_dma(q + 1);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + 64 * wc + 32 * ni + 8 * g + 4 * h;
-                const f32x4 sc = *(const f32x4*)(p.wscale + n);
-                const f32x4 bi = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                *(f32x4*)(smem + STG + (wr * 32 + r32) * ROWB + (wc * 32 + 8 * g + 4 * h) * 4) = scaled(mi, ni, g, sc, bi);
-            }
+            for (int g = 0; g < 4; ++g)
+                *(f32x4*)(smem + STG + (wr * 32 + r32) * ROWB + (wc * 32 + 8 * g + 4 * h) * 4) = scaled(mi, ni, g, scv[ni][g], biv[ni][g]);
             if (q + 1 < 8) wait_vmcnt<4>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_waitcnt(0xc07f);
             barrier();
@@ -239,11 +379,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(Gemm8Args p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = 64 * wc + 32 * ni + 8 * g + 4 * h;
-                const f32x4 sc = *(const f32x4*)(p.wscale + n0 + nl);
-                const f32x4 bi = p.bias ? *(const f32x4*)(p.bias + n0 + nl) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mi = 0; mi < C::MT; ++mi) {
-                    f32x4 v = scaled(mi, ni, g, sc, bi);
+                    f32x4 v = scaled(mi, ni, g, scv[ni][g], biv[ni][g]);
                     if (act == ACT_GELU) v = gelu_erf_fast4(v);
                     else if (act == ACT_RELU) {
 #pragma unroll
@@ -260,41 +398,45 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(Gemm8Args p) {
             *(f32x4*)(p.out8 + (size_t)(m0 + rr) * p.N + n0 + ch * 16) = v;
         }
     } else {
-        // 16-bit output (qkv): 2 passes of 128 rows (mi = 2 q, 2 q + 1 of both wave rows) x 256 columns
+        // 16-bit output (qkv): one pass, 256 rows x 256 columns
         constexpr int ROWB = 256 * 2 + 16;
-        static_assert(128 * ROWB <= C::LDS, "epilogue LDS map");
+        static_assert(256 * ROWB <= C::LDS, "epilogue LDS map");
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
-            for (int ni = 0; ni < C::NT; ++ni)
+            for (int g = 0; g < 4; ++g) {
+                const int nl = 64 * wc + 32 * ni + 8 * g + 4 * h;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int nl = 64 * wc + 32 * ni + 8 * g + 4 * h;
-                    const f32x4 sc = *(const f32x4*)(p.wscale + n0 + nl);
-                    const f32x4 bi = p.bias ? *(const f32x4*)(p.bias + n0 + nl) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int mi = 0; mi < C::MT; ++mi) {
+                    f32x4 v = scaled(mi, ni, g, scv[ni][g], biv[ni][g]);
+                    if (act == ACT_GELU) v = gelu_erf_fast4(v);
+                    else if (act == ACT_RELU) {
 #pragma unroll
-                    for (int mm = 0; mm < 2; ++mm) {
-                        f32x4 v = scaled(2 * q + mm, ni, g, sc, bi);
-                        if (act == ACT_GELU) v = gelu_erf_fast4(v);
-                        else if (act == ACT_RELU) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                        }
-                        typename T::vec4 o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
-                        *(typename T::vec4*)(smem + (wr * 64 + mm * 32 + r32) * ROWB + nl * 2) = o;
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                     }
-                }
-            __syncthreads();
+                    typename T::vec4 o;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int c = it * 512 + tid, rr = c >> 5, ch = c & 31;
-                const int m = m0 + (rr >> 6) * 128 + q * 64 + (rr & 63);
-                const f32x4 v = *(const f32x4*)(smem + rr * ROWB + ch * 16);
-                *(f32x4*)((char*)p.out16 + ((size_t)m * p.N + n0) * 2 + ch * 16) = v;
+                    for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+                    *(typename T::vec4*)(smem + (wr * 128 + mi * 32 + r32) * ROWB + nl * 2) = o;
+                }
             }
-            if (q == 0) __syncthreads();
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int c = it * 512 + tid, rr = c >> 5, ch = c & 31;
+            const f32x4 v = *(const f32x4*)(smem + rr * ROWB + ch * 16);
+            *(f32x4*)((char*)p.out16 + ((size_t)(m0 + rr) * p.N + n0) * 2 + ch * 16) = v;
+        }
+    }
+    if constexpr (DBG) {
+        if (wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long wt3 = wall_clock64();
+            if (lane == 0) {
+                unsigned long long* r = p.dbg + (size_t)blockIdx.x * 4;
+                r[0] = wt0; r[1] = wt1; r[2] = wt2; r[3] = wt3;
+                if (blockIdx.x == 0) { r[0] = wt0; p.dbg[(size_t)gridDim.x * 4] = mt2 - mt1; p.dbg[(size_t)gridDim.x * 4 + 1] = wt2 - wt1; }
+            }
         }
     }
 }

@@ -570,28 +570,71 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
     return WM_BY_PREC((launch_gemm16_t<BF16>(h, s, a)), (launch_gemm16_t<FP16>(h, s, a)));
 }
 
-// fp8 GEMM (gemm8.h).  T16 = type of a 16-bit output.
+// fp8 GEMM (gemm8.h).  prec16 = type of a 16-bit output.  WM_GEMM8_BK=128|64 picks the K-step variant (A/B runs).
+template <class T16, int BKB>
+int launch_gemm8_t(wm_handle* h, hipStream_t s, Gemm8Args a, int grid, double flops, double bytes) {
+    using G = G8<BKB>;
+    static const bool dbg = getenv("WM_GEMM8_DBG") != nullptr;          // dev: per-workgroup wall-clock stamps of the 5th launch
+    static int dbg_count = 0;
+    if (dbg && ++dbg_count == 5) {
+        unsigned long long* buf = nullptr;
+        HIP_TRY(hipMalloc((void**)&buf, (size_t)grid * 32 + 16 + 256));
+        HIP_TRY(hipMemset(buf, 0, (size_t)grid * 32 + 16 + 256));
+        a.dbg = buf;
+        WM_TRY(set_max_lds((const void*)gemm8_kernel<T16, BKB, true>, G::LDS));
+        hipLaunchKernelGGL((gemm8_kernel<T16, BKB, true>), dim3(grid), dim3(512), G::LDS, s, a);
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned long long> r((size_t)grid * 4 + 2 + 32);
+        HIP_TRY(hipMemcpy(r.data(), buf, r.size() * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(buf));
+        unsigned long long t_min = ~0ull, t_max = 0;
+        double pro = 0, loop = 0, epi = 0;
+        for (int i = 0; i < grid; ++i) {
+            t_min = std::min(t_min, r[i * 4]); t_max = std::max(t_max, r[i * 4 + 3]);
+            pro += (double)(r[i * 4 + 1] - r[i * 4]); loop += (double)(r[i * 4 + 2] - r[i * 4 + 1]); epi += (double)(r[i * 4 + 3] - r[i * 4 + 2]);
+        }
+        {
+            const unsigned* mk = (const unsigned*)(r.data() + (size_t)grid * 4 + 2);
+            for (int g = 0; g < 2; ++g)
+                for (int st = 0; st < 4; ++st) {
+                    fprintf(stderr, "  [gemm8 dbg] group %d step %d marks (cycles rel. to group-0 step-4 mark 0):", g, st + 4);
+                    for (int k = 0; k < 6; ++k) fprintf(stderr, " %7d", (int)(mk[g * 24 + st * 6 + k] - mk[0]));
+                    fprintf(stderr, "\n");
+                }
+        }
+        fprintf(stderr, "[gemm8 dbg] workgroup 0 main loop: %llu shader cycles in %.2f us -> %.0f MHz\n", r[(size_t)grid * 4], r[(size_t)grid * 4 + 1] * 0.01,
+                (double)r[(size_t)grid * 4] / (r[(size_t)grid * 4 + 1] * 0.01));
+        fprintf(stderr, "[gemm8 dbg] BK=%d M=%d N=%d K=%d out=%s: span %.2f us; per workgroup avg: prologue %.2f us, loop %.2f us (%.0f ns per 128 of K), epilogue %.2f us; %d workgroups\n",
+                BKB, a.M, a.N, a.K, a.residual ? "f32+res" : (a.out8 ? "fp8" : "16"), (t_max - t_min) * 0.01, pro / grid * 0.01, loop / grid * 0.01,
+                loop / grid * 10.0 / (a.K / 128.0), epi / grid * 0.01, grid);
+        return 0;
+    }
+    WM_TRY(set_max_lds((const void*)gemm8_kernel<T16, BKB>, G::LDS));
+    Bracket br(h, s, WM_KCLASS_GEMM16, flops, bytes);
+    hipLaunchKernelGGL((gemm8_kernel<T16, BKB>), dim3(grid), dim3(512), G::LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_gemm8(wm_handle* h, hipStream_t s, int prec16, const void* A, const void* W, const float* wscale, const float* bias,
                  const float* res, float* out32, void* out16, void* out8, int M, int N, int K, int act) {
-    if (M <= 0 || N <= 0 || K <= 0 || M % G8::BM || N % G8::BN || K % G8::BKB || K / G8::BKB < 2)
-        return fail("gemm8: shape M=%d N=%d K=%d must be multiples of %d/%d/%d with K >= %d", M, N, K, G8::BM, G8::BN, G8::BKB, 2 * G8::BKB);
+    const int bk = getenv("WM_GEMM8_BK") ? atoi(getenv("WM_GEMM8_BK")) : 128;     // 128 measured >= 64 on every block shape
+    if (M <= 0 || N <= 0 || K <= 0 || M % G8_BM || N % G8_BN || K % 128 || K < 256)
+        return fail("gemm8: shape M=%d N=%d K=%d must be multiples of %d/%d/128 with K >= 256", M, N, K, G8_BM, G8_BN);
     if (!A || !W || !wscale) return fail("gemm8: null operand");
     const int modes = (res != nullptr) + (out8 != nullptr) + (res == nullptr && out8 == nullptr && out16 != nullptr);
     if (modes != 1 || (res && !out32 && !out16) || (!res && out32)) return fail("gemm8: outputs must be (residual + out32 [+ out16]) | out8 | out16");
-    Gemm8Args a{(const unsigned char*)A, (const unsigned char*)W, wscale, bias, res, out32, (u16*)out16, (unsigned char*)out8, M, N, K, act};
-    const int grid = (M / G8::BM) * (N / G8::BN);
+    Gemm8Args a{(const unsigned char*)A, (const unsigned char*)W, wscale, bias, res, out32, (u16*)out16, (unsigned char*)out8, M, N, K, act, nullptr};
+    const int grid = (M / G8_BM) * (N / G8_BN);
     count_variant(WM_GEMM_FP8_256);
-    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * M * (double)N * K,
-               (double)M * K + (double)N * K + (res ? 8.0 : 0.0) * M * N + (out16 ? 2.0 : 0.0) * M * N + (out8 ? 1.0 : 0.0) * M * N);
-    if (prec16 == WM_PREC_FP16) {
-        WM_TRY(set_max_lds((const void*)gemm8_kernel<FP16>, G8::LDS));
-        hipLaunchKernelGGL((gemm8_kernel<FP16>), dim3(grid), dim3(512), G8::LDS, s, a);
-    } else {
-        WM_TRY(set_max_lds((const void*)gemm8_kernel<BF16>, G8::LDS));
-        hipLaunchKernelGGL((gemm8_kernel<BF16>), dim3(grid), dim3(512), G8::LDS, s, a);
+    const double flops = 2.0 * M * (double)N * K;
+    const double bytes = (double)M * K + (double)N * K + (res ? 8.0 : 0.0) * M * N + (out16 ? 2.0 : 0.0) * M * N + (out8 ? 1.0 : 0.0) * M * N;
+    if (bk == 128) {
+        if (prec16 == WM_PREC_FP16) return launch_gemm8_t<FP16, 128>(h, s, a, grid, flops, bytes);
+        return launch_gemm8_t<BF16, 128>(h, s, a, grid, flops, bytes);
     }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    if (prec16 == WM_PREC_FP16) return launch_gemm8_t<FP16, 64>(h, s, a, grid, flops, bytes);
+    return launch_gemm8_t<BF16, 64>(h, s, a, grid, flops, bytes);
 }
 
 // 3x3 / pad 1 convolution over an NHWC [B,64,64,C] 16-bit activation as an implicit GEMM (no im2col buffer):
@@ -703,9 +746,10 @@ int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
 }
 
 int launch_encoder_attention(wm_handle* h, hipStream_t s, int prec, const void* qkv, const float* qkv_bias,
-                             const float* rel_h, const float* rel_w, void* out, int batch, int heads, int hd, int window) {
+                             const float* rel_h, const float* rel_w, void* out, int batch, int heads, int hd, int window, void* out8 = nullptr) {
     const int D = heads * hd;
     AttnArgs a{};
+    a.out8 = (unsigned char*)out8;
     a.q = (const u16*)qkv; a.k = (const u16*)qkv + D; a.v = (const u16*)qkv + 2 * D;
     a.out = (u16*)out;
     a.q_stride = a.k_stride = a.v_stride = 3 * D;
@@ -1210,10 +1254,9 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
             WM_TRY(launch_layernorm_block(h, s, P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D));
             WM_TRY(launch_gemm8(h, s, WM_PREC_BF16, h->xn16, W8(b + "attn.qkv.weight"), W32(h, b + "attn.qkv.weight.wscale"), W32(h, b + "attn.qkv.bias"),
                                 nullptr, nullptr, h->qkv16, nullptr, M, 3 * D, D, ACT_NONE));
+            // the attention kernels write their output directly as e4m3 (the A operand of proj)
             WM_TRY(launch_encoder_attention(h, s, WM_PREC_BF16, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
-                                            W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14));
-            WM_TRY(launch_simple(h, s, (double)M * D * 3.0, cvt_16_to_fp8_kernel<BF16>, dim3(grid_for((int64_t)M * D / 8)), dim3(256), (const u16*)h->ao16,
-                                 (unsigned char*)h->ao8, (int64_t)M * D / 8));
+                                            W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14, h->ao8));
             WM_TRY(launch_gemm8(h, s, WM_PREC_BF16, h->ao8, W8(b + "attn.proj.weight"), W32(h, b + "attn.proj.weight.wscale"), W32(h, b + "attn.proj.bias"),
                                 h->resid, h->resid, nullptr, nullptr, M, D, D, ACT_NONE));
             WM_TRY(launch_layernorm_block(h, s, P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D));
