@@ -1,10 +1,21 @@
-# One gpurun call: kernel-trace stats, PMC traffic passes, then the default bench line.  usage: bash tools/profile_round.sh r1f
+# One gpurun call: kernel-trace stats, PMC traffic + utilisation passes, then the default bench lines (bf16 and fp8).
+# usage: bash tools/profile_round.sh r2
 set -e
-TAG=${1:-r1x}
+TAG=${1:-r2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_${TAG}_bench.log 2>&1
-echo "stats done"
-rocprofv3 -i tools/pmc_traffic.txt --kernel-trace --output-format csv -d gpurun_out/pmc_$TAG -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_${TAG}.log 2>&1
-echo "pmc done"
-python3 bench.py > gpurun_out/bench_${TAG}_default.json 2> gpurun_out/bench_${TAG}_default.err
-tail -1 gpurun_out/bench_${TAG}_default.json | cut -c1-300
+mkdir -p gpurun_out/$TAG
+for P in bf16 fp8; do
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_$P -- python3 bench.py --precision $P --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/$TAG/prof_${P}_bench.log 2>&1
+cp gpurun_out/prof_${TAG}_$P/*/*kernel_stats.csv gpurun_out/$TAG/${P}_kernel_stats.csv
+echo "stats $P done"
+rocprofv3 -i tools/pmc_traffic.txt --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$P -- python3 bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/$TAG/pmc_$P.log 2>&1
+python3 tools/pmc_summarize.py gpurun_out/pmc_${TAG}_$P gpurun_out/$TAG/${P}_pmc_traffic.json "rocprofv3 -i tools/pmc_traffic.txt --kernel-trace -- python3 bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-roofline" 16 $P > /dev/null
+echo "pmc traffic $P done"
+rocprofv3 -i tools/pmc_util.txt --kernel-trace --output-format csv -d gpurun_out/pmcu_${TAG}_$P -- python3 bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/$TAG/pmcu_$P.log 2>&1
+python3 tools/pmc_kernel.py gpurun_out/pmcu_${TAG}_$P gemm16v5_kernel gemm8_kernel attn_window_kernel attn_global_kernel layernorm_tiled > gpurun_out/$TAG/${P}_pmc_util.txt
+echo "pmc util $P done"
+done
+python3 bench.py > gpurun_out/$TAG/bench_bf16_default.json 2> gpurun_out/$TAG/bench_bf16_default.err
+python3 bench.py --precision fp8 > gpurun_out/$TAG/bench_fp8.json 2> gpurun_out/$TAG/bench_fp8.err
+tail -1 gpurun_out/$TAG/bench_bf16_default.json | cut -c1-200
+tail -1 gpurun_out/$TAG/bench_fp8.json | cut -c1-200
