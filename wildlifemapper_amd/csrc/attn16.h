@@ -414,8 +414,8 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
 // Rel-pos bias per wave: T[c][i] = q_c . table[i] by one MFMA pass over the 64-row
 // table image (rel_h rows 0..26, rel_w rows 32..58), staged per wave in LDS; each
 // lane then gathers its query's 14 + 14 values U[kh] = T[qh-kh+13], V[kw] = T[32+qw-kw+13]
-// into registers.  The key loop is fully unrolled, so a score element's (kh,kw)
-// are compile-time constants per lane half and the bias is two register selects.
+// into registers.  Key slots are laid out 14 x 16 (two zero pad columns), so that in the
+// fully unrolled key loop a score's bias is one add of two registers (see the key loop).
 // ---------------------------------------------------------------------------
 template <int HD> struct WindowLds {
     using G = AttnGeom<HD>;
@@ -466,10 +466,10 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int e = tid + i * NTHR;
-            const int key = e / G::CH, ch = e % G::CH;
-            s16x8 kv8 = s16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv8 = kv8;                      // rows >= 196 stay zero
-            if (key < NTOK) {
-                const int y = wy * WS + key / WS, x = wx * WS + key % WS;
+            const int key = e / G::CH, ch = e % G::CH;                                  // key slot = 16 kh + kw (kw 14, 15: zero rows)
+            s16x8 kv8 = s16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv8 = kv8;
+            if ((key & 15) < WS) {
+                const int y = wy * WS + (key >> 4), x = wx * WS + (key & 15);
                 if (y < GRID && x < GRID) {
                     const u16* row = base + (size_t)(y * GRID + x) * p.q_stride;
                     kv8 = *(const s16x8*)(row + D + ch * 8);
@@ -574,35 +574,33 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
         }
         SoftmaxState<G::NDT> st;
         st.init();
-        // 196 keys = 3 tiles of 64 + 4: fewer, longer softmax steps (each step's max -> exchange -> exp -> convert chain is
-        // latency the 1.75 waves per SIMD cannot hide); the key loop stays fully unrolled so the bias is register selects
-        auto bias_of = [&](int key0, int key1) {         // rel-pos bias of this lane's element: key0 (half 0) / key1 (half 1)
-            const float b0 = key0 < NTOK ? U[(key0 < NTOK ? key0 : 0) / WS] + V[(key0 < NTOK ? key0 : 0) % WS] : 0.f;
-            const float b1 = key1 < NTOK ? U[(key1 < NTOK ? key1 : 0) / WS] + V[(key1 < NTOK ? key1 : 0) % WS] : 0.f;
-            return h ? b1 : b0;
-        };
+        // Key slots are laid out 14 rows (kh) x 16 columns (kw; 14 and 15 are zero rows, masked through the bias): a 32-key MFMA
+        // tile is 2 kh rows, so for accumulator register r of lane half h the key is kh = 2 (tile) + (r >> 3),
+        // kw = (r & 3) + 8 ((r >> 2) & 1) + 4 h: kh is a compile-time constant and kw depends on the lane only through h.
+        // Each lane therefore pre-selects its 8 kw values once (Vsel, -1e30 for the two pad columns) and a score's rel-pos
+        // bias is ONE add of two registers, U[kh] + Vsel[idx]; the 224 slots are 3 steps of 64 keys + 1 of 32.
+        float Vsel[8];
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8) {
+            const int kw0 = (i8 & 3) + 8 * (i8 >> 2);                              // half 0; half 1: + 4
+            Vsel[i8] = h ? (kw0 + 4 < WS ? V[kw0 + 4 < WS ? kw0 + 4 : 0] : -1e30f) : V[kw0 < WS ? kw0 : 0];
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             f32x16 s[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k0 = 64 * j + 32 * t + (r & 3) + 8 * (r >> 2);
-                    s[t][r] = bias_of(k0, k0 + 4);
-                }
+                for (int r = 0; r < 16; ++r) s[t][r] = U[4 * j + 2 * t + (r >> 3)] + Vsel[(r & 3) + 4 * ((r >> 2) & 1)];
             qk_tile<T, HD, 2>(s, qf, sK + j * 64 * G::KS, lane);
             softmax_pv<T, HD, 2>(st, s, c1, 0.f, 64, sV + j * 64 * G::VS, lane);
         }
         {
             f32x16 s[1];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k0 = 192 + (r & 3) + 8 * (r >> 2);
-                s[0][r] = bias_of(k0, k0 + 4);
-            }
+            for (int r = 0; r < 16; ++r) s[0][r] = U[12 + (r >> 3)] + Vsel[(r & 3) + 4 * ((r >> 2) & 1)];
             qk_tile<T, HD, 1>(s, qf, sK + 192 * G::KS, lane);
-            softmax_pv<T, HD, 1>(st, s, c1, 0.f, NTOK - 192, sV + 192 * G::VS, lane);
+            softmax_pv<T, HD, 1>(st, s, c1, 0.f, 32, sV + 192 * G::VS, lane);
         }
         {
             int b, win, head;
