@@ -229,7 +229,7 @@ def main() -> None:
             traffic = None
             traffic_src = None
             try:   # HBM bytes per GEMM launch from the PMC passes committed under profiles/ (collected offline with rocprofv3)
-                for name in ("r2_pmc_traffic.json", "r1g_pmc_traffic.json"):
+                for name in (("r2_pmc_traffic.json" if a.precision == "bf16" else f"r2_{a.precision}_pmc_traffic.json"), "r1g_pmc_traffic.json"):
                     with open(os.path.join(ROOT, "profiles", name)) as f:
                         t = json.load(f)
                     # the committed counters belong to one workload: use them only for that one
@@ -248,9 +248,9 @@ def main() -> None:
                         "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
                         "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
                         "ms_per_step_with_events": round(prof_elapsed / a.steps * 1e3, 3),
-                        "sustained_clock_note": "power-limited: in-kernel s_memtime / wall clock (WM_GEMM_DBG=1) reads ~1.5 GHz at the "
-                                                "31st GEMM of a step (1.79 GHz isolated, 1.34 GHz in a GEMM-only loop), i.e. ~1.57 "
-                                                "PFLOP/s of dense bf16 MFMA at the sustained clock; DESIGN.md section 5",
+                        "sustained_clock_note": "power-limited: in-kernel s_memtime / wall clock (WM_GEMM_DBG=1 / WM_GEMM8_DBG=1) reads ~1.5 GHz "
+                                                "at the 31st bf16 GEMM of a step (1.79 GHz isolated) and 1.6-1.9 GHz in the fp8 GEMM; "
+                                                "DESIGN.md section 5",
                         "gemm_instances_per_step": gemm_instances}
             classes = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["launches"] // a.steps,
                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
