@@ -174,6 +174,22 @@ def test_gemm16_dispatch_and_values_at_model_shapes(M, N, K, act, variant):
     assert G.rel_l2(o16.float(), y) < OUT16_TOL[prec]
 
 
+@pytest.mark.parametrize("M,N,K,act", [(32768, 3840, 1280, 0), (32768, 5120, 1280, 1), (32768, 3072, 1024, 0)])
+def test_gemm16_persistent_instance_bit_identical(M, N, K, act, monkeypatch):
+    """The opt-in persistent instance (WM_GEMM_PERSIST=1: one workgroup per CU walks the tiles, next tile's first K-steps
+    requested during the epilogue; measured slower, kept off) computes the same bits as the default kernel."""
+    prec, dev = "bf16", G.dev()
+    a = G.to16(torch.randn(M, K, device=dev), prec)
+    w = G.to16(torch.randn(N, K, device=dev) / math.sqrt(K), prec)
+    bias = torch.randn(N, device=dev)
+    monkeypatch.setenv("WM_GEMM_PERSIST", "0")
+    _, base = G.gemm16(a, w, bias, None, 0, act, prec, want32=False, want16=True)
+    monkeypatch.setenv("WM_GEMM_PERSIST", "1")
+    for _ in range(3):
+        _, pers = G.gemm16(a, w, bias, None, 0, act, prec, want32=False, want16=True)
+        assert torch.equal(base, pers)
+
+
 def test_gemm16_kernels_agree_bitwise():
     """A tile's result must not depend on which GEMM kernel its batch size selects (batch-invariant
     bit for bit): the same rows through the half-width kernel (M = 4096) and through the staggered 256 x 320 kernel

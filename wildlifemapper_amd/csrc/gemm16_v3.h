@@ -48,7 +48,7 @@ template <int BN, int WN> struct G3 {
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N <= 10, "extend the table");
+    static_assert(N >= 0 && N <= 12, "extend the table");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -59,7 +59,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 }
 
 template <class T, int BN, int WN, int AMODE = 0>

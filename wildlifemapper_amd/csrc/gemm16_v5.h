@@ -34,9 +34,17 @@ namespace wm {
 // K-steps 8..17, every workgroup its wall-clock entry / first barrier / loop end / stores-acknowledged stamps, into
 // p.zero_page.  The instrumented instance is a separate kernel; the product instance carries none of it.
 // LNF: the fp32-residual epilogue also LayerNorms the finished rows (see its code and Gemm16Args::ln_*).
-template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false>
+// PERSIST (round 2): one workgroup per CU walks the tiles tile = blockIdx.x + i * gridDim.x (gridDim.x a multiple of 8, so a
+// workgroup's tiles keep its XCD's id range of the grouped order) and requests the NEXT tile's first K-steps into the
+// ring while it runs the current tile's epilogue in the LDS above them: the workgroup hand-over on a CU (0.6-1.6 us) and
+// the ring fill (1.7-3.3 us until the first barrier) measured with the DBG timeline no longer sit in front of every 37-44 us
+// K loop.  LDS map with PERSIST (160 KiB): 16-bit / fp32 outputs stage in [2 STAGE, ...) and steps 0, 1 of the next tile
+// land in slots 0, 1; the fp32 + residual epilogue needs 121 KiB (staging + two landing buffers) and lives in [STAGE, ...),
+// so only step 0 is requested ahead (slot 0) and step 1 follows when the next tile starts.
+template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     using C = G3<BN, 4>;
+    static_assert(!PERSIST || (!DBG && !LNF && NSLOT == 3), "the persistent instance is the plain product kernel");
     constexpr int AHEAD = NSLOT - 1;                       // K-steps of DMA in flight
     // timing experiments of tools/gemm_bench.py (--act 256 / 512 / 1024): compiled in only with -DWM_GEMM_TIMING_BITS=1
     constexpr bool TB = WM_GEMM_TIMING_BITS != 0;
@@ -53,54 +61,72 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     const char* Ab = (const char*)p.A;
     const char* Wb = (const char*)p.W;
 
-    int m0, n0;
-    {
-        const int tilesM = p.M / C::BM, tilesN = p.N / BN;
-        const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tilesM = p.M / C::BM, tilesN = p.N / BN, total_tiles = tilesM * tilesN;
+    auto tile_origin = [&](int tile, int& tm0, int& tn0) {
+        const int t = xcd_remap(tile, total_tiles);
         const int gm = p.group_m > 0 ? p.group_m : G16_GROUP_M;
         const int per_group = gm * tilesN;
         const int group = t / per_group;
         const int first_m = group * gm;
         const int gsz = min(gm, tilesM - first_m);
         const int in_group = t - group * per_group;
-        m0 = (first_m + in_group % gsz) * C::BM;
-        n0 = (in_group / gsz) * BN;
-    }
+        tm0 = (first_m + in_group % gsz) * C::BM;
+        tn0 = (in_group / gsz) * BN;
+    };
+    int m0, n0;
+    int tile = blockIdx.x;
+    tile_origin(tile, m0, n0);
+    int pre_issued = 0;                                    // PERSIST: K-steps of the current tile already requested
 
     const unsigned lane_off = (unsigned)(lane >> 2) * (unsigned)(K * 2) + (unsigned)((((lane & 3) ^ ((0 - (lane >> 4)) & 3))) << 4);
     const size_t row_bytes = (size_t)K * 2;
     // DMA pieces of this wave for K-step s into ring slot `slot`; EXTRA: waves 0-3 also carry the remainder W piece
-    auto stage = [&](int slot, int s, auto extra_tag) {
+    // The wave-uniform part of a DMA source address is pinned to SGPRs (opaque to the optimiser), so that the instruction takes
+    // the saddr form (SGPR pair + 32-bit per-lane offset) instead of a 64-bit per-lane address that is kept as a VGPR pair per
+    // piece and advanced with a v_lshl_add_u64 per piece and K-step: 8-10 registers and 4-5 vector instructions per step less.
+    auto sgpr_ptr = [](const char* ptr) {
+        unsigned long long b = (unsigned long long)ptr;
+        asm volatile("" : "+s"(b));
+        return (const char*)b;
+    };
+    auto stage_at = [&](int slot, int s, auto extra_tag, int m0, int n0) {     // (m0, n0): the tile the pieces belong to
         constexpr bool EXTRA = decltype(extra_tag)::value;
         if (dbg_noissue && s >= AHEAD) return;
         if (dbg_nodma) s = 0;
 #pragma unroll
         for (int i = 0; i < C::A_PIECES; ++i) {
             const int seg = wave * C::A_PIECES + i;
-            const char* base = Ab + (size_t)(m0 + seg * 16) * row_bytes + (size_t)s * 64;
+            const char* base = sgpr_ptr(Ab + (size_t)(m0 + seg * 16) * row_bytes + (size_t)s * 64);
             __builtin_amdgcn_global_load_lds(base + lane_off, WM_LDS_PTR(smem + slot * C::STAGE + seg * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < C::W_LO + (EXTRA ? 1 : 0); ++i) {
             const int seg = i < C::W_LO ? wave * C::W_LO + i : C::WAVES * C::W_LO + wave;
-            const char* base = Wb + (size_t)(n0 + seg * 16) * row_bytes + (size_t)s * 64;
+            const char* base = sgpr_ptr(Wb + (size_t)(n0 + seg * 16) * row_bytes + (size_t)s * 64);
             __builtin_amdgcn_global_load_lds(base + lane_off, WM_LDS_PTR(smem + slot * C::STAGE + C::A_BYTES + seg * 1024), 16, 0, 0);
         }
     };
+    auto stage = [&](int slot, int s, auto extra_tag) { stage_at(slot, s, extra_tag, m0, n0); };
 
     const int frag_off = fr * 64 + ((fq ^ ((0 - (fr >> 2)) & 3)) << 4);
-    const int rd_a = (wr * 128) * 64 + frag_off;
-    const int rd_w = C::A_BYTES + (wc * C::WCOLS) * 64 + frag_off;
+    const int rd_a_k = (wr * 128) * 64 + frag_off;
+    const int rd_w_k = C::A_BYTES + (wc * C::WCOLS) * 64 + frag_off;
 
     f32x4 acc[C::MT][C::NT];
-#pragma unroll
-    for (int i = 0; i < C::MT; ++i)
-#pragma unroll
-        for (int j = 0; j < C::NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     typename T::vec8 wf[C::NT], af[C::MT];
 
     auto read_frags = [&](int slot) {
         const char* sS = smem + slot * C::STAGE;
+        int rd_a = rd_a_k, rd_w = rd_w_k;
+        if constexpr (PERSIST) {
+            // recomputed from v_mbcnt every K-step (8 VALU): kept across the tile loop, hipcc spills these two offsets (or the
+            // lane id they derive from) and reloads them here behind a vmcnt(0), which drains the DMA ring every step
+            const int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // lane id from EXEC: no live register
+            const int fr_k = l & 15, fq_k = l >> 4;
+            const int fo = fr_k * 64 + ((fq_k ^ ((0 - (fr_k >> 2)) & 3)) << 4);
+            rd_a = (wr * 128) * 64 + fo;
+            rd_w = C::A_BYTES + (wc * C::WCOLS) * 64 + fo;
+        }
         af[0] = *(const typename T::vec8*)(sS + rd_a);
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) wf[i] = *(const typename T::vec8*)(sS + rd_w + i * 1024);
@@ -115,11 +141,21 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     };
     auto inc = [](int v) { return v == NSLOT - 1 ? 0 : v + 1; };
     auto dec = [](int v) { return v == 0 ? NSLOT - 1 : v - 1; };
+    constexpr int RP_CPR = BN * 4 / 16, RP_PW = RP_CPR / 16;       // residual tile: 16-byte chunks per row; DMA pieces per wave and pass
+    // PERSIST_16: the persistent instance that is built serves the 16-bit-output GEMMs only (qkv, lin1: no residual, no fp32
+    // output): with the residual epilogue's address arithmetic also in the tile loop the kernel spills (accumulators included)
+    constexpr bool PERSIST_16 = PERSIST;
+    const bool res_late = PERSIST && !PERSIST_16 && p.residual != nullptr;    // pass 0 of the residual is requested AFTER the first K-steps
     auto wait_step = [&](int s, auto extra_tag) {          // this wave's pieces of step s have landed
         constexpr int P = C::P_LO + (decltype(extra_tag)::value ? 1 : 0);
         if (dbg_noissue) { wait_vmcnt<0>(); return; }
         if constexpr (AHEAD == 3) {
             if (s + 2 < ns) { wait_vmcnt<2 * P>(); return; }
+        }
+        if constexpr (PERSIST) {
+            // steps 0 and 1 of a tile: the residual's pass-0 pieces sit between stage(1) and stage(2) in issue order and may
+            // stay in flight (vmcnt leaves the N youngest operations: stage(s + 1) and those RP_PW pieces)
+            if (res_late && s < 2 && s + 1 < ns) { wait_vmcnt<P + RP_PW>(); return; }
         }
         if (s + 1 < ns) wait_vmcnt<P>(); else wait_vmcnt<0>();
     };
@@ -137,10 +173,16 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     };
 
     // fp32 residual (proj / lin2: out = residual + A W^T + b): the residual tile comes in by LDS-DMA, 32 rows (16 per
-    // wave group) per epilogue pass, one pass ahead; pass 0 is requested here and lands beside the ring.
-    constexpr int RP_CPR = BN * 4 / 16, RP_PW = RP_CPR / 16;       // 16-byte chunks per row; DMA pieces per wave and pass
-    constexpr int RES_L0 = NSLOT * C::STAGE, RES_L1 = 45056, RES_BYTES = 32 * BN * 4;
-    static_assert(32 * (BN * 4 + 16) <= RES_L1 && RES_L1 + RES_BYTES <= NSLOT * C::STAGE, "epilogue LDS map");
+    // wave group) per epilogue pass, one pass ahead; pass 0 is requested at the start of the tile and lands beside the ring.
+    constexpr int RES_BYTES = 32 * BN * 4;
+    constexpr int EPI_BASE = PERSIST ? 2 * C::STAGE : 0;                          // staging of the 16-bit / fp32 epilogues
+    constexpr int RES_STG = PERSIST ? C::STAGE : 0;                               // staging of the residual epilogue
+    constexpr int RES_L1 = PERSIST ? RES_STG + 32 * (BN * 4 + 16) : 45056;
+    constexpr int RES_L0 = PERSIST ? RES_L1 + RES_BYTES : NSLOT * C::STAGE;
+    constexpr int LDS_TOTAL = PERSIST ? 160 * 1024 : NSLOT * C::STAGE + RES_BYTES;
+    static_assert(RES_STG + 32 * (BN * 4 + 16) <= RES_L1 && RES_L0 >= NSLOT * C::STAGE && RES_L0 + RES_BYTES <= LDS_TOTAL &&
+                  (PERSIST ? RES_L1 + RES_BYTES <= RES_L0 : RES_L1 + RES_BYTES <= NSLOT * C::STAGE) && RES_L1 % 16 == 0 && RES_L0 % 16 == 0,
+                  "epilogue LDS map");
     const int res_mod = p.res_mod > 0 ? p.res_mod : p.M;
     const bool res_wrap = res_mod != p.M;                           // broadcast residual (pos_embed): row m % res_mod
     auto res_dma = [&](int q) {
@@ -154,13 +196,20 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             __builtin_amdgcn_global_load_lds((const char*)(p.residual + (size_t)m * p.N + n0 + ch * 4), WM_LDS_PTR(dst + piece * 1024), 16, 0, 0);
         }
     };
-    if (p.residual) res_dma(0);
+
+    for (;;) {                                              // tiles of this workgroup (one iteration unless PERSIST)
+#pragma unroll
+    for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!PERSIST_16) { if (!res_late && p.residual) res_dma(0); }
 
     if (wr == 0) {
         using EX = std::integral_constant<bool, (C::W_REM > 0)>;
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i)
-            if (i < ns) stage(i, i, EX{});
+            if (i >= pre_issued && i < ns) stage(i, i, EX{});
+        if (res_late) res_dma(0);
         int slot = 0;
 #pragma unroll 1
         for (int s = 0; s < ns; ++s) {
@@ -183,7 +232,8 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         using EX = std::false_type;
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i)
-            if (i < ns) stage(i, i, EX{});
+            if (i >= pre_issued && i < ns) stage(i, i, EX{});
+        if (res_late) res_dma(0);
         int slot = 0;
 #pragma unroll 1
         for (int s = 0; s < ns; ++s) {
@@ -217,16 +267,46 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     // 128 rows (16-bit output) or 64 rows (fp32 output), each thread then moves 16-byte chunks that are consecutive
     // along the row, and the residual is read the same way.
     const int act = p.act & 0xff;
+    // PERSIST: the epilogue's per-lane offsets are derived from an opaque copy of the thread id, so that the compiler
+    // recomputes them per tile instead of hoisting them out of the tile loop and spilling them around the K loop
+    // (cdna_hip_programming.md, persistent-structure pitfalls)
+    int tid_e = tid;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid_e));
+    const int fr_e = tid_e & 15, fq_e = (tid_e & 63) >> 4;
     f32x4 bias_v[C::NT];
 #pragma unroll
     for (int ni = 0; ni < C::NT; ++ni)
-        bias_v[ni] = p.bias ? *(const f32x4*)(p.bias + n0 + wc * C::WCOLS + ni * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias_v[ni] = p.bias ? *(const f32x4*)(p.bias + n0 + wc * C::WCOLS + ni * 16 + fq_e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): this wave's fragment reads are back
     barrier();                                              // every wave is done with the ring
     if constexpr (DBG) we[0] = wall_clock64();
+    // PERSIST: the next tile's first K-steps go into the (now idle) low ring slots while this tile's epilogue runs above them
+    int next_tile = 0, nm0 = 0, nn0 = 0, next_issued = 0;
+    bool has_next = false;
+    auto prefetch_next = [&](int steps) {                   // every wave issues its own pieces, as in the K loop
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (i < steps && i < ns) {
+                if (wr == 0) stage_at(i, i, std::integral_constant<bool, (C::W_REM > 0)>{}, nm0, nn0);
+                else stage_at(i, i, std::false_type{}, nm0, nn0);
+            }
+    };
+    if constexpr (PERSIST) {
+        // the bias values are ordinary loads: make the compiler wait for them HERE (nothing else is in flight), not at their
+        // first use behind the prefetch, where hipcc would drain every outstanding LDS-DMA with vmcnt(0)
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni) asm volatile("" ::"v"(bias_v[ni]));
+        next_tile = tile + (int)gridDim.x;
+        has_next = next_tile < total_tiles;
+        if (has_next) {
+            tile_origin(next_tile, nm0, nn0);
+            if (PERSIST_16 || p.residual == nullptr) { prefetch_next(2); next_issued = 2; }   // residual path: one step, after its pass 0 (below)
+        }
+    }
     // one straight-line instance per activation (a per-fragment runtime branch costs more than the stores)
     auto epilogue = [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
+    const int tid = tid_e, fr = fr_e, fq = fq_e;           // shadow the kernel-scope values (see tid_e)
     auto finish = [&](f32x4 v, int ni) {
         v += bias_v[ni];
         if constexpr (ACT == ACT_GELU) {
@@ -345,10 +425,14 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             rec[0] = lt1; rec[1] = lt2; rec[2] = lt3; rec[3] = wall_clock64();
         }
     } else
-    if (p.out32 == nullptr && p.residual == nullptr) {
-        // 16-bit staging: 2 passes of 4 row-fragments; LDS row = BN * 2 + 16 bytes
-        constexpr int ROWB = BN * 2 + 16, CPR = BN * 2 / 16, MTP = 4, ROWS = 2 * MTP * 16;
-        static_assert(ROWS * ROWB <= NSLOT * C::STAGE && (ROWS * CPR) % 512 == 0, "epilogue staging");
+    if (PERSIST_16 || (p.out32 == nullptr && p.residual == nullptr)) {
+        // 16-bit staging: 2 passes of 4 row-fragments (PERSIST: 4 passes of 2, above the two slots the next tile's first
+        // K-steps are landing in); LDS row = BN * 2 + 16 bytes
+        constexpr int ROWB = BN * 2 + 16, CPR = BN * 2 / 16, MTP = PERSIST ? 2 : 4, ROWS = 2 * MTP * 16;
+        static_assert(EPI_BASE + ROWS * ROWB <= LDS_TOTAL && (ROWS * CPR) % 512 == 0, "epilogue staging");
+        auto epi_sync = [&]() {                              // PERSIST: a raw barrier (a __syncthreads would drain the prefetch)
+            if constexpr (PERSIST) { __builtin_amdgcn_s_waitcnt(0xc07f); barrier(); } else __syncthreads();
+        };
 #pragma unroll
         for (int q = 0; q < C::MT / MTP; ++q) {
 #pragma unroll
@@ -359,21 +443,21 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
                     typename T::vec4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
-                    *(typename T::vec4*)(smem + (wr * MTP * 16 + mm * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 2) = o;
+                    *(typename T::vec4*)(smem + EPI_BASE + (wr * MTP * 16 + mm * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 2) = o;
                 }
-            __syncthreads();
-            if constexpr (DBG) we[1 + 2 * q] = wall_clock64();
+            epi_sync();
+            if constexpr (DBG) { if (q < 2) we[1 + 2 * q] = wall_clock64(); }
 #pragma unroll
             for (int it = 0; it < ROWS * CPR / 512; ++it) {
                 const int c = it * 512 + tid, r = c / CPR, ch = c - r * CPR;
                 const int m = m0 + (r / (MTP * 16)) * 128 + q * MTP * 16 + (r % (MTP * 16));
-                const f32x4 v = *(const f32x4*)(smem + r * ROWB + ch * 16);
+                const f32x4 v = *(const f32x4*)(smem + EPI_BASE + r * ROWB + ch * 16);
                 if (!dbg_nostore) *(f32x4*)((char*)p.out16 + ((size_t)m * p.N + n0) * 2 + ch * 16) = v;
             }
-            if constexpr (DBG) we[2 + 2 * q] = wall_clock64();
-            if (q + 1 < C::MT / MTP) __syncthreads();
+            if constexpr (DBG) { if (q < 2) we[2 + 2 * q] = wall_clock64(); }
+            if (q + 1 < C::MT / MTP) epi_sync();
         }
-    } else if (p.residual != nullptr) {
+    } else if (!PERSIST_16 && p.residual != nullptr) {
         // fp32 + residual: 8 passes of one row-fragment (32 rows).  Pass q: request the residual rows of pass q + 1,
         // stage this pass's accumulators, wait for this wave's residual pieces of pass q (everything but the DMA
         // just issued is complete: the C stores of pass q - 1 are older and have had a pass to be acknowledged),
@@ -385,16 +469,21 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             if (q + 1 < C::MT) res_dma(q + 1);
 #pragma unroll
             for (int ni = 0; ni < C::NT; ++ni)
-                *(f32x4*)(smem + (wr * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 4) = finish(acc[q][ni], ni);
+                *(f32x4*)(smem + RES_STG + (wr * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 4) = finish(acc[q][ni], ni);
             if (q + 1 < C::MT) wait_vmcnt<RP_PW>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): staging writes done
             barrier();
+            if constexpr (PERSIST) {
+                // the next tile's step 0 into slot 0 (below this epilogue's LDS), issued after pass 0's wait so that no
+                // epilogue wait has to sit out its round trip: by pass 1's wait it has had a pass to land
+                if (q == 0 && has_next) { prefetch_next(1); next_issued = 1; }
+            }
             const char* land = smem + ((q & 1) ? RES_L1 : RES_L0);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int c = it * 512 + tid, r = c / RP_CPR, ch = c - r * RP_CPR;
                 const int m = m0 + (r >> 4) * 128 + q * 16 + (r & 15);
-                const f32x4 v = *(const f32x4*)(smem + r * ROWB + ch * 16) + *(const f32x4*)(land + c * 16);
+                const f32x4 v = *(const f32x4*)(smem + RES_STG + r * ROWB + ch * 16) + *(const f32x4*)(land + c * 16);
                 if (dbg_nostore) { if (v[0] == 12345.678f) p.out16[0] = 1; continue; }
                 if (p.out32) *(f32x4*)(p.out32 + (size_t)m * p.N + n0 + ch * 4) = v;
                 if (p.out16) {
@@ -409,23 +498,26 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
                 barrier();
             }
         }
-    } else {
+    } else if constexpr (!PERSIST_16) {
         // fp32 staging: 4 passes of 2 row-fragments; LDS row = BN * 4 + 16 bytes
         constexpr int ROWB = BN * 4 + 16, CPR = BN * 4 / 16, MTP = 2, ROWS = 2 * MTP * 16;
-        static_assert(ROWS * ROWB <= NSLOT * C::STAGE && (ROWS * CPR) % 512 == 0, "epilogue staging");
+        static_assert(EPI_BASE + ROWS * ROWB <= LDS_TOTAL && (ROWS * CPR) % 512 == 0, "epilogue staging");
+        auto epi_sync = [&]() {
+            if constexpr (PERSIST) { __builtin_amdgcn_s_waitcnt(0xc07f); barrier(); } else __syncthreads();
+        };
 #pragma unroll
         for (int q = 0; q < C::MT / MTP; ++q) {
 #pragma unroll
             for (int mm = 0; mm < MTP; ++mm)
 #pragma unroll
                 for (int ni = 0; ni < C::NT; ++ni)
-                    *(f32x4*)(smem + (wr * MTP * 16 + mm * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 4) = finish(acc[q * MTP + mm][ni], ni);
-            __syncthreads();
+                    *(f32x4*)(smem + EPI_BASE + (wr * MTP * 16 + mm * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 4) = finish(acc[q * MTP + mm][ni], ni);
+            epi_sync();
 #pragma unroll
             for (int it = 0; it < ROWS * CPR / 512; ++it) {
                 const int c = it * 512 + tid, r = c / CPR, ch = c - r * CPR;
                 const int m = m0 + (r / (MTP * 16)) * 128 + q * MTP * 16 + (r % (MTP * 16));
-                f32x4 v = *(const f32x4*)(smem + r * ROWB + ch * 16);
+                f32x4 v = *(const f32x4*)(smem + EPI_BASE + r * ROWB + ch * 16);
                 if (dbg_nostore) { if (v[0] == 12345.678f) p.out16[0] = 1; continue; }
                 if (p.out32) *(f32x4*)(p.out32 + (size_t)m * p.N + n0 + ch * 4) = v;
                 if (p.out16) {
@@ -435,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
                     *(typename T::vec4*)(p.out16 + (size_t)m * p.N + n0 + ch * 4) = o;
                 }
             }
-            if (q + 1 < C::MT / MTP) __syncthreads();
+            if (q + 1 < C::MT / MTP) epi_sync();
         }
     }
     };
@@ -446,6 +538,15 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         else if (act == ACT_RELU) epilogue(std::integral_constant<int, ACT_RELU>{});
         else epilogue(std::integral_constant<int, ACT_NONE>{});
     }
+    if constexpr (PERSIST) {
+        if (!has_next) break;
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // this wave's reads of the epilogue staging / landing buffers are back
+        barrier();                                          // before anyone's K-loop DMA (slot 2, landing buffer 0) reuses that LDS
+        tile = next_tile; m0 = nm0; n0 = nn0; pre_issued = next_issued;
+    } else {
+        break;
+    }
+    }                                                       // tiles
     if constexpr (DBG) {
         if (wave == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // C stores of this wave acknowledged

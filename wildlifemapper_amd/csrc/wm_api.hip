@@ -406,6 +406,20 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
             return 0;
         }
     }
+    // Persistent instance (one workgroup per CU walks its tiles and requests the next tile's first K-steps during the epilogue),
+    // 16-bit-output GEMMs only.  OFF by default: bit-identical, but measured 7-15 % slower at BN = 320 and +-2 % at BN = 256
+    // (tools/ab_persist.py); WM_GEMM_PERSIST=1 enables it.
+    if constexpr (NSLOT == 3) {
+        const char* pe = getenv("WM_GEMM_PERSIST");
+        const int cus = num_cus();
+        if (pe && atoi(pe) != 0 && grid >= 2 * cus && cus % 8 == 0 && !a.residual && !a.out32 && a.out16) {
+            constexpr int LDSP = 160 * 1024;
+            WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, NSLOT, false, false, true>, LDSP));
+            hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, NSLOT, false, false, true>), dim3(cus), dim3(512), LDSP, s, a);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, NSLOT>), dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
