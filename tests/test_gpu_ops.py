@@ -343,9 +343,12 @@ def _ref_encoder_attention(qkv, bias16, rel_h, rel_w, B, heads, hd, window, prec
     return o.reshape(B * 4096, D)
 
 
+@pytest.mark.parametrize("kernel", ["1", "2"])
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("heads,hd", [(2, 80), (3, 64)])
-def test_window_attention(prec, heads, hd):
+def test_window_attention(prec, heads, hd, kernel, monkeypatch):
+    # kernel 1 = the default; 2 = the opt-in LDS-DMA / exact-softmax kernel (attn_win2.h, WM_ATTN_WIN=2, read per launch)
+    monkeypatch.setenv("WM_ATTN_WIN", kernel)
     B, D = 2, heads * hd
     dev = G.dev()
     qkv = G.to16(torch.randn(B * 4096, 3 * D, device=dev), prec)
@@ -358,9 +361,12 @@ def test_window_attention(prec, heads, hd):
     assert (out.float() - ref).abs().max().item() < (0.06 if prec == "bf16" else 0.01)
 
 
+@pytest.mark.parametrize("kernel", ["1", "2"])
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("heads,hd", [(2, 80), (2, 64)])
-def test_global_attention_relpos(prec, heads, hd):
+def test_global_attention_relpos(prec, heads, hd, kernel, monkeypatch):
+    # kernel 1 = the default; 2 = the opt-in two-blocks-per-wave kernel (attn_glob2.h, WM_ATTN_GLOBAL=2, read per launch)
+    monkeypatch.setenv("WM_ATTN_GLOBAL", kernel)
     B, D = 1, heads * hd
     dev = G.dev()
     qkv = G.to16(torch.randn(B * 4096, 3 * D, device=dev), prec)

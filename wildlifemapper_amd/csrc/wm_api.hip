@@ -18,6 +18,8 @@
 
 #include "../../include/wm_hip.h"
 #include "attn16.h"
+#include "attn_win2.h"
+#include "attn_glob2.h"
 #include "dec_kernels.h"
 #include "fft_kernels.h"
 #include "gemm16.h"
@@ -219,6 +221,7 @@ struct wm_handle {
     std::map<std::string, uint16_t*> w16;
     std::map<std::string, uint8_t*> w8;     // WM_PREC_FP8: e4m3 weights of the blocks' GEMMs; their per-channel scales live in w32[name + ".wscale"]
     uint8_t* ao8 = nullptr;                 // attention output as e4m3 (A operand of proj)
+    uint16_t* win_cpage = nullptr;          // constant page of the LDS-DMA window attention (attn_win2.h): [3D + 80] 16-bit
     std::map<std::string, float*> w32;
     std::vector<void*> allocs;
     Profiler prof;
@@ -725,6 +728,18 @@ int launch_layernorm_block(wm_handle* h, hipStream_t s, int prec, const float* x
 
 template <class T16, int HD, bool REL>
 int launch_attn_global_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int batch, int kclass) {
+    // WM_ATTN_GLOBAL=2: two query blocks per wave, one wave per SIMD (attn_glob2.h): correct (same tests), 12-18 % slower than
+    // the default kernel on the encoder shape and 35-55 % slower at head_dim 128; kept as the measured experiment
+    const char* e = getenv("WM_ATTN_GLOBAL");
+    if (e && atoi(e) == 2 && a.nq % 256 == 0) {
+        using L2 = Global2Lds<HD, REL>;
+        WM_TRY(set_max_lds((const void*)attn_global2_kernel<T16, HD, REL>, L2::TOTAL));
+        Bracket br(h, s, kclass, 4.0 * batch * a.heads * (double)a.nq * a.nk * HD, 0.0);
+        const int nqb = a.nq / 256;
+        hipLaunchKernelGGL((attn_global2_kernel<T16, HD, REL>), dim3(nqb * a.heads * batch), dim3(256), L2::TOTAL, s, a, nqb);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     using L = GlobalLds<HD, REL>;
     WM_TRY(set_max_lds((const void*)attn_global_kernel<T16, HD, REL>, L::TOTAL));
     Bracket br(h, s, kclass, 4.0 * batch * a.heads * (double)a.nq * a.nk * HD, 0.0);
@@ -747,14 +762,43 @@ int launch_attn_global_p(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
 
 template <class T16, int HD>
 int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int batch) {
-    using L = WindowLds<HD>;
-    WM_TRY(set_max_lds((const void*)attn_window_kernel<T16, HD>, L::TOTAL));
-    // useful work only: 4096 real queries x 196 keys
     const int num_cu = num_cus();
     const int nitems = 25 * a.heads * batch;
     const int grid = nitems < num_cu ? nitems : num_cu;
-    Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);
-    hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(grid), dim3(448), L::TOTAL, s, a, nitems);
+    // default: first-generation kernel (register staging, online softmax).  WM_ATTN_WIN=2: the LDS-DMA / exact-softmax kernel
+    // (attn_win2.h): correct (same tests) but 27 % slower at B = 16 (334 vs 263 us), kept as the measured experiment
+    const char* e = getenv("WM_ATTN_WIN");
+    if (!(e && atoi(e) == 2)) {
+        using L = WindowLds<HD>;
+        WM_TRY(set_max_lds((const void*)attn_window_kernel<T16, HD>, L::TOTAL));
+        Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);   // useful work only
+        hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(grid), dim3(448), L::TOTAL, s, a, nitems);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    using L = Window2Lds<HD>;
+    const int D = a.heads * HD;
+    // constant page of the DMA sources (16-bit qkv bias, zero chunk, ones chunk): the handle's, or a per-device one for the
+    // handle-less single-op entry (tests; not for concurrent streams)
+    uint16_t* cpage = h ? h->win_cpage : nullptr;
+    if (!cpage) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        static std::map<int, std::pair<uint16_t*, int>> pages;
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        auto& pg = pages[dev];
+        if (pg.second < 3 * D + 128) {
+            if (pg.first) HIP_TRY(hipFree(pg.first));
+            pg.first = nullptr; pg.second = 0;
+            HIP_TRY(hipMalloc((void**)&pg.first, (size_t)(3 * D + 128) * 2));
+            pg.second = 3 * D + 128;
+        }
+        cpage = pg.first;
+    }
+    WM_TRY(set_max_lds((const void*)attn_window2_kernel<T16, HD>, L::TOTAL));
+    Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);       // useful work only
+    hipLaunchKernelGGL((attn_win2_cpage_kernel<T16>), dim3(4), dim3(256), 0, s, a.qkv_bias, cpage, 3 * D);
+    hipLaunchKernelGGL((attn_window2_kernel<T16, HD>), dim3(grid), dim3(448), L::TOTAL, s, a, nitems, (const u16*)cpage);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1042,6 +1086,7 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     A(hfc, B * 1024 * 1024 * 4); A(tsz_default, B * 2 * 4);
     A(fftR, B * FFT_N * FFT_L * sizeof(float2)); A(fft_tw, FFT_N * sizeof(float2));
     A(kpe, (size_t)T * OUTC * 4);
+    A(win_cpage, (3 * D + 128) * 2);
     A(records, B * NQ * sizeof(wm_box_record));
 #undef A
     if (r) { wm_destroy(h); return r; }
