@@ -515,3 +515,26 @@ def test_input_pipeline_resize_bit_exact_vs_pil(golden_dir):
         assert not got[b][:, 512:, :].any() and not got[b][:, :, 768:].any()
     with pytest.raises(RuntimeError, match="canvas"):
         tiles_from_u8(torch.zeros(1, 2000, 2000, 3, dtype=torch.uint8, device=G.dev()), resize=(1100, 0))
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """The N > 1 path of bench.py (self-launch through torch.distributed.run, tile sharding, the per-step all-gather of box
+    records, max-over-ranks timing, one JSON line on rank 0) rehearsed with two ranks sharing this box's single GPU.  The
+    collective runs on gloo here (RCCL refuses two ranks on one device); on a multi-GPU node the driver launches the same
+    script with the nccl backend.  Three GPU processes in total (this one + 2 ranks), below the box's process guard."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--model", "vit_b",
+           "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["tiles_per_step"] == 4 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["steps"] == 2 and line["warmup"] == 1
+    assert "all-gather of box records" in line["config"]["parallelism"]
+    assert line["roofline"]["achieved"] > 0 and line["cpu_baseline"] is None
