@@ -13,7 +13,7 @@ What the reference cannot produce here (torchvision missing): MedSAM.fft's
 Grayscale and the NMS step.  For those the fixture stores the oracle's own
 output, flagged `pinned=0`.
 
-Usage:  python oracle/gen_golden.py [--only small|vit_b|vit_h] [--out tests/golden]
+Usage:  python oracle/gen_golden.py [--only small|vit_b|vit_l|vit_h] [--out tests/golden]
 """
 from __future__ import annotations
 
@@ -291,6 +291,8 @@ def main() -> None:
         gen_coco_subset(a.out)
     if a.only in ("all", "vit_b"):
         gen_e2e(a.out, "vit_b", n_tiles=2, first_tile=0)
+    if a.only in ("all", "vit_l"):
+        gen_e2e(a.out, "vit_l", n_tiles=1, first_tile=5)
     if a.only in ("all", "vit_h"):
         gen_e2e(a.out, "vit_h", n_tiles=1, first_tile=0)
 

@@ -329,10 +329,17 @@ def test_cpu_tensor_fails_loudly():
         m(NestedTensor(torch.zeros(1, 3, 1024, 1024), None), None)
 
 
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_vit_l_vs_reference_golden(prec, golden_dir):
+    """The registry's third entry (build_sam.py:30-41: 1024 wide, 24 blocks, global blocks 5/11/17/23; 256-column GEMM tiles,
+    4-tile LayerNorm, hd 64 attention) against tests/golden/e2e_vit_l.npz: the reference's own modules on tile 5
+    (oracle/gen_golden.py --only vit_l): stem, HFC adaptor, 9 block taps, embedding, logits, boxes, NMS index list."""
+    _run_vs_golden("vit_l", prec, golden_dir)
+
+
 def test_vit_l_vs_oracle():
-    """The registry's third entry (build_sam.py:30-41: 1024 wide, 24 blocks, global blocks 5/11/17/23; 256-column GEMM
-    tiles, 4-tile LayerNorm, hd 64 attention).  No reference fixture is committed for it, so the check is against the
-    CPU oracle (which the ViT-B / ViT-H fixtures pin) on one tile, bf16 mode, the same 1e-3 bar."""
+    """Same model against the CPU oracle run live on the same tile (bf16 mode, the same 1e-3 bar): ties the oracle, the
+    fixture and the HIP path together for the third registry entry."""
     m, post = _model("vit_l", "bf16")
     x = torch.from_numpy(synth.make_batch(5, 1))
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}

@@ -171,6 +171,25 @@ def test_oracle_end_to_end_vs_reference_fixture(golden_dir):
     assert det["nms_index"].tolist() == fx["pp0_nms_index"].tolist()
 
 
+def test_oracle_end_to_end_matches_reference_fixture_vit_l(golden_dir):
+    """The oracle on the registry's third entry (ViT-L: 1024 wide, 24 blocks, hd 64) against tests/golden/e2e_vit_l.npz,
+    which oracle/gen_golden.py --only vit_l produced by running the reference's modules on tile 5: logits, boxes, per-channel
+    embedding means, NMS list (fp32 on both sides)."""
+    fx = np.load(os.path.join(golden_dir, "e2e_vit_l.npz"))
+    assert int(fx["n_tiles"]) == 1
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict("vit_l").items()}
+    x = torch.from_numpy(synth.make_batch(int(fx["first_tile"]), 1))
+    taps = {}
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    out = O.model_forward(x, sd, O.OracleCfg.from_model_type("vit_l"), taps)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert rel(out["pred_logits"].numpy(), fx["pred_logits"]) < 5e-6
+    assert np.abs(out["pred_boxes"].numpy() - fx["pred_boxes"]).max() < 5e-6
+    np.testing.assert_allclose(taps["embedding"].double().mean(dim=(2, 3)).numpy(), fx["emb_chan_mean"], atol=2e-6)
+    det = O.detect(O.postprocess(out["pred_logits"], out["pred_boxes"], torch.tensor([[1024, 1024]]))[0])
+    assert det["nms_index"].tolist() == fx["pp0_nms_index"].tolist()
+
+
 def test_pil_resize_restatement(golden_dir):
     """oracle/pil_resize.py (the val transform's resize, dataloader_coco.py:288 -> PIL bilinear) against vectors PIL itself
     produced (tests/golden/resize_pil.npz, oracle/gen_golden.py --only resize): bit-exact, and the output-size rule of
