@@ -378,9 +378,11 @@ def test_global_attention_relpos(prec, heads, hd, kernel, monkeypatch):
     assert G.rel_l2(out.float(), ref) < 2 * OUT16_TOL[prec]
 
 
-def test_global_attention_forces_rescale():
+@pytest.mark.parametrize("kernel", ["1", "2"])
+def test_global_attention_forces_rescale(kernel, monkeypatch):
     """One key row spiked against the queries so the running max jumps at a late tile (online-softmax
-    rescale branch; cdna guide rule 26)."""
+    rescale branch; cdna guide rule 26).  Both global kernels (WM_ATTN_GLOBAL, read per launch)."""
+    monkeypatch.setenv("WM_ATTN_GLOBAL", kernel)
     heads, hd, prec, dev = 1, 80, "bf16", G.dev()
     D = heads * hd
     x = torch.randn(4096, 3 * D, device=dev) * 0.3
