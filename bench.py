@@ -7,8 +7,9 @@ A "step" is one pass of the hot path over one batch of synthetic 1024x1024 tiles
 resident in HBM: FFT high-pass -> ViT-H encoder -> detection decoder -> PostProcess + NMS
 (`--workload full`, the default), or the encoder alone (`--workload encoder`).  Default batch is
 16 tiles per GPU = BASELINE.json configs[2], the largest single-GPU configuration (and configs[3]'s
-per-GPU share: 128 tiles over 8 GPUs); `--batch 4 --workload encoder` is configs[1] literally,
-`--precision fp8` configs[4].  With N > 1 tiles shard data-parallel, one process per GPU, and every
+per-GPU share: 128 tiles over 8 GPUs); `--batch 4 --workload encoder --precision bf16` is configs[1] literally,
+`--precision fp8` configs[4].  Default operand type: fp16 (same MFMA rate as bf16; the mode that meets the 1e-3 logits bar
+on every weight set tried); `--precision bf16` is +3.9 % tiles/s.  With N > 1 tiles shard data-parallel, one process per GPU, and every
 step ends with the single fixed-size RCCL all-gather of box records (dist.py); per-GPU work is
 constant -> weak scaling.  `--gpus N` without a torch.distributed.run environment starts
 `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process (before this
@@ -131,7 +132,9 @@ def _config_name(a, B: int, world: int) -> str:
     if a.precision == "fp8":
         return "BASELINE.json configs[4]" if (B == 16 and world == 1 and a.workload == "full") else "fp8 variant, not the configs[4] batch"
     if a.workload == "encoder":
-        return "BASELINE.json configs[1]" if (B == 4 and world == 1) else "encoder only, not the configs[1] batch"
+        if B == 4 and world == 1:
+            return "BASELINE.json configs[1]" if a.precision == "bf16" else "configs[1]'s shape with fp16 operands (configs[1] names bf16: --precision bf16)"
+        return "encoder only, not the configs[1] batch"
     if B == 16:
         return "BASELINE.json configs[2]" if world == 1 else (f"BASELINE.json configs[3]: {16 * world} tiles over {world} GPUs" if world == 8
                                                                else f"configs[2] per GPU, {world} GPUs")
@@ -145,8 +148,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU per step (16 = BASELINE.json configs[2])")
     ap.add_argument("--model", default="vit_h")
-    ap.add_argument("--precision", default=os.environ.get("WM_PRECISION", "bf16"), choices=["bf16", "fp16", "fp8"],
-                    help="bf16 (default, BASELINE.json configs[1-3]) | fp16 | fp8 (configs[4]; tolerance re-stated, see config.tolerance)")
+    ap.add_argument("--precision", default=os.environ.get("WM_PRECISION", "fp16"), choices=["bf16", "fp16", "fp8"],
+                    help="operand type of the MFMA GEMMs / attention: fp16 (default: meets the 1e-3 logits bar on every weight set tried) | "
+                         "bf16 (the type BASELINE.json configs[1] names; same MFMA rate, +3.9 %% tiles/s, logits 0.7e-3 .. 2.0e-3 depending on "
+                         "the weights) | fp8 (configs[4]; tolerance re-stated, see config.tolerance)")
     ap.add_argument("--workload", default="full", choices=["full", "encoder"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -229,7 +234,7 @@ def main() -> None:
             traffic = None
             traffic_src = None
             try:   # HBM bytes per GEMM launch from the PMC passes committed under profiles/ (collected offline with rocprofv3)
-                for name in (("r2_pmc_traffic.json" if a.precision == "bf16" else f"r2_{a.precision}_pmc_traffic.json"), "r1g_pmc_traffic.json"):
+                for name in (("r2_pmc_traffic.json" if a.precision == "bf16" else f"r2_{a.precision}_pmc_traffic.json"), "r1g_pmc_traffic.json"):   # bf16 keeps its round-2 file name
                     with open(os.path.join(ROOT, "profiles", name)) as f:
                         t = json.load(f)
                     # the committed counters belong to one workload: use them only for that one
@@ -270,7 +275,9 @@ def main() -> None:
                        "weights": "seed 0 synthetic (random init)",
                        "tolerance": ("re-stated for fp8 (DESIGN.md section 3): logits within 5e-2 relative of the fp32 CPU forward, mAP50 vs the CPU "
                                      "reference's detections >= 0.8" if a.precision == "fp8"
-                                     else "logits within 1e-3 relative of the fp32 CPU forward, identical NMS index lists")},
+                                     else ("logits within 1e-3 relative of the fp32 CPU forward, identical NMS index lists" if a.precision == "fp16"
+                                           else "bf16 operands: logits within 1e-3 relative of the fp32 CPU forward on synth weight seed 0 (7.2-8.2e-4), "
+                                                "2.0e-3 on seed 1; identical NMS index lists on both (DESIGN.md section 3)"))},
             "model_tflops": round(tiles_per_s * flops_tile / 1e12, 1) if flops_tile else None,
             "frac_of_mfma_peak_whole_path": round(tiles_per_s * flops_tile / 1e12 / (PEAK_TFLOPS.get(a.precision, 2500.0) * world), 4) if flops_tile else None,
             "roofline": roofline, "kernel_classes": classes,

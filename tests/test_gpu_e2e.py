@@ -5,10 +5,11 @@
 Tolerances.  north_star asks for logits within 1e-3 relative of the reference CPU forward and
 identical box indices after NMS.  "Relative" is measured as ||x - ref||_2 / ||ref||_2 over the
 (B,51,8) logits.  Operand precision sets what is reachable (DESIGN.md "Precision"):
-  fp16 operands: 1e-3 on logits on both weight profiles, identical NMS indices;
+  fp16 operands (the default): 1e-3 on logits on both weight profiles and both weight seeds, identical NMS indices;
   bf16 operands (transformer blocks in bf16; stem, HFC adaptor and neck always run fp16 operands):
-                 1e-3 on logits on the baseline profile (measured 8.3e-4 ViT-H, 4.7e-4 ViT-B), identical NMS
-                 indices; the embedding itself is checked at 5e-3 (8-bit mantissas give ~3e-3 per GEMM).
+                 1e-3 on logits on the baseline profile with weight seed 0 (measured 7.2-8.3e-4 ViT-H on five tiles, 4.7e-4
+                 ViT-B) but 2.0e-3 with seed 1; identical NMS indices on both; the embedding itself is checked at 5e-3
+                 (8-bit mantissas give ~3e-3 per GEMM).
 """
 import os
 
@@ -519,6 +520,34 @@ def test_vit_h_more_tiles_vs_reference_golden(prec, golden_dir):
         assert max(errs) < LOGIT_TOL[prec], errs            # north_star's 1e-3 on every tile
         assert berr < 5 * LOGIT_TOL[prec], berr
         assert all(same), same
+
+
+def test_vit_h_second_weight_seed_vs_reference_golden(golden_dir):
+    """A DIFFERENT set of synthetic weights (synth seed 1; tests/golden/e2e_vit_h_seed1.npz: the reference modules on tiles 0
+    and 1, oracle/gen_golden.py --only vit_h_seed1).  fp16 operands (the default mode) meet north_star's 1e-3 here as on seed 0
+    (measured 1.7-1.8e-4).  bf16 operands do NOT: 2.0e-3 (seed 0: 7.2-8.2e-4); what bf16 reaches depends on the weights, which is
+    why it is not the default.  Its bound here is what was measured + 25 %.  NMS lists identical in both.
+    The resident model's parameters are replaced in place (the hub re-packs them) and restored afterwards."""
+    fx = np.load(os.path.join(golden_dir, "e2e_vit_h_seed1.npz"))
+    n, first, seed = int(fx["n_tiles"]), int(fx["first_tile"]), int(fx["weight_seed"])
+    m, _ = _model("vit_h", "bf16")
+    base = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    try:
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict("vit_h", seed).items()}, strict=True)
+        x = torch.from_numpy(synth.make_batch(first, n)).to(G.dev())
+        for prec in ("fp16", "bf16"):
+            m._hub.set_precision(prec)
+            with torch.no_grad():
+                out = m.detect(x, torch.tensor([[1024, 1024]] * n))
+            lg = out["pred_logits"].cpu().numpy()
+            rec = split_records(out["records"].cpu())
+            errs = [float(np.linalg.norm(lg[t] - fx["pred_logits"][t]) / np.linalg.norm(fx["pred_logits"][t])) for t in range(n)]
+            same = [_nms_positions(rec, t) == fx[f"pp{t}_nms_index"].tolist() for t in range(n)]
+            print(f"[vit_h/{prec}/seed {seed}] logits per tile " + " ".join(f"{e:.2e}" for e in errs) + f" NMS identical: {same}")
+            assert max(errs) < (LOGIT_TOL[prec] if prec == "fp16" else 2.5e-3), errs
+            assert all(same), same
+    finally:
+        m.load_state_dict(base, strict=True)
 
 
 def test_input_pipeline_resize_bit_exact_vs_pil(golden_dir):

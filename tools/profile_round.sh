@@ -1,10 +1,11 @@
-# One gpurun call: kernel-trace stats, PMC traffic + utilisation passes, then the default bench lines (bf16 and fp8).
-# usage: bash tools/profile_round.sh r2
+# One gpurun call: kernel-trace stats, PMC traffic + utilisation passes per precision, then the bench lines.
+# usage: bash tools/profile_round.sh r2 ["fp16 bf16 fp8"]
 set -e
 TAG=${1:-r2}
+PRECS=${2:-"fp16 bf16 fp8"}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
-for P in bf16 fp8; do
+for P in $PRECS; do
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_$P -- python3 bench.py --precision $P --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/$TAG/prof_${P}_bench.log 2>&1
 cp gpurun_out/prof_${TAG}_$P/*/*kernel_stats.csv gpurun_out/$TAG/${P}_kernel_stats.csv
 echo "stats $P done"
@@ -15,7 +16,7 @@ rocprofv3 -i tools/pmc_util.txt --kernel-trace --output-format csv -d gpurun_out
 python3 tools/pmc_kernel.py gpurun_out/pmcu_${TAG}_$P gemm16v5_kernel gemm8_kernel attn_window_kernel attn_global_kernel layernorm_tiled > gpurun_out/$TAG/${P}_pmc_util.txt
 echo "pmc util $P done"
 done
-python3 bench.py > gpurun_out/$TAG/bench_bf16_default.json 2> gpurun_out/$TAG/bench_bf16_default.err
-python3 bench.py --precision fp8 > gpurun_out/$TAG/bench_fp8.json 2> gpurun_out/$TAG/bench_fp8.err
-tail -1 gpurun_out/$TAG/bench_bf16_default.json | cut -c1-200
-tail -1 gpurun_out/$TAG/bench_fp8.json | cut -c1-200
+for P in $PRECS; do
+python3 bench.py --precision $P > gpurun_out/$TAG/bench_$P.json 2> gpurun_out/$TAG/bench_$P.err
+tail -1 gpurun_out/$TAG/bench_$P.json | cut -c1-200
+done
