@@ -34,8 +34,8 @@ extern "C" {
 /* operand type of the transformer blocks' MFMA GEMMs / attention (accumulation, residual stream, LayerNorm
  * statistics, softmax and the whole decoder are fp32; the stem, the HFC adaptor and the neck -- 2.9 % of the
  * FLOPs -- always use fp16 operands, see DESIGN.md "Precision") */
-#define WM_PREC_BF16 0   /* north_star default: bf16 MFMA                         */
-#define WM_PREC_FP16 1   /* fp16 MFMA, same rate, 3 more mantissa bits */
+#define WM_PREC_BF16 0   /* the type north_star names: bf16 MFMA; logits 0.7e-3 .. 2.0e-3 of the fp32 reference, weight-dependent */
+#define WM_PREC_FP16 1   /* fp16 MFMA, same rate, 3 more mantissa bits: 1.7-2.4e-4; what the Python drop-in selects by default */
 #define WM_PREC_FP8 2    /* BASELINE.json configs[4]: the blocks' qkv / proj / MLP GEMMs on the block-scaled fp8 MFMA
                             (OCP e4m3 weights with one fp32 scale per output channel, e4m3 activations at unit scale,
                             fp32 accumulation); attention stays bf16.  Tolerance re-stated in DESIGN.md section 3. */
