@@ -495,15 +495,17 @@ def test_vit_h_fp8_batch16_vs_reference_golden(golden_dir):
     assert bool(torch.isfinite(lg).all())
 
 
+@pytest.mark.parametrize("fixture", ["e2e_vit_h_tiles1to4.npz", "e2e_vit_h_smooth.npz"])
 @pytest.mark.parametrize("prec", ["fp16", "bf16", "fp8"])
-def test_vit_h_more_tiles_vs_reference_golden(prec, golden_dir):
-    """The end-to-end tolerance on FOUR more ViT-H tiles (1..4; tests/golden/e2e_vit_h_tiles1to4.npz holds the reference modules'
-    logits / boxes and the NMS lists, oracle/gen_golden.py --only vit_h_tiles), run as one batch: per tile, logits within the
-    bar of the precision and, for the 16-bit modes, the NMS index list identical."""
-    fx = np.load(os.path.join(golden_dir, "e2e_vit_h_tiles1to4.npz"))
+def test_vit_h_more_tiles_vs_reference_golden(prec, fixture, golden_dir):
+    """The end-to-end tolerance on more ViT-H inputs, each fixture run as one batch: four more noise tiles (1..4) and two
+    tiles with low-frequency content (`synth.make_tile_u8(smooth=True)`: pass-band and stop-band energy for the FFT high-pass).
+    The fixtures hold the reference modules' logits / boxes and the NMS lists (oracle/gen_golden.py --only vit_h_tiles /
+    vit_h_smooth).  Per tile: logits within the bar of the precision and, for the 16-bit modes, the NMS index list identical."""
+    fx = np.load(os.path.join(golden_dir, fixture))
     n, first = int(fx["n_tiles"]), int(fx["first_tile"])
     m, _ = _model("vit_h", prec)
-    x = torch.from_numpy(synth.make_batch(first, n)).to(G.dev())
+    x = torch.from_numpy(synth.make_batch(first, n, smooth="smooth" in fx.files)).to(G.dev())
     with torch.no_grad():
         out = m.detect(x, torch.tensor([[1024, 1024]] * n))
     lg, bx = out["pred_logits"].cpu().numpy(), out["pred_boxes"].cpu().numpy()
@@ -513,7 +515,7 @@ def test_vit_h_more_tiles_vs_reference_golden(prec, golden_dir):
         errs.append(float(np.linalg.norm(lg[t] - fx["pred_logits"][t]) / np.linalg.norm(fx["pred_logits"][t])))
         same.append(_nms_positions(rec, t) == fx[f"pp{t}_nms_index"].tolist())
     berr = float(np.abs(bx - fx["pred_boxes"]).max())
-    print(f"[vit_h/{prec}] tiles {first}..{first + n - 1}: logits per tile " + " ".join(f"{e:.2e}" for e in errs) + f" boxes_maxabs={berr:.2e} NMS identical: {same}")
+    print(f"[vit_h/{prec}] {fixture} tiles {first}..{first + n - 1}: logits per tile " + " ".join(f"{e:.2e}" for e in errs) + f" boxes_maxabs={berr:.2e} NMS identical: {same}")
     if prec == "fp8":
         assert max(errs) < FP8_LOGIT_TOL and berr < FP8_BOX_TOL, (errs, berr)
     else:
