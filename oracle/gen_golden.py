@@ -13,7 +13,7 @@ What the reference cannot produce here (torchvision missing): MedSAM.fft's
 Grayscale and the NMS step.  For those the fixture stores the oracle's own
 output, flagged `pinned=0`.
 
-Usage:  python oracle/gen_golden.py [--only small|vit_b|vit_l|vit_h|vit_h_tiles|vit_h_seed1|vit_h_smooth] [--out tests/golden]
+Usage:  python oracle/gen_golden.py [--only small|vit_b|vit_l|vit_h|vit_h_tiles|vit_h_seed1|vit_h_smooth|vit_h_padded] [--out tests/golden]
 """
 from __future__ import annotations
 
@@ -238,7 +238,7 @@ def gen_e2e(out: str, model_type: str, n_tiles: int, first_tile: int) -> None:
           "kept:", [len(fx[f'pp{b}_nms_index']) for b in range(n_tiles)])
 
 
-def gen_e2e_outputs(out: str, model_type: str, n_tiles: int, first_tile: int, seed: int = 0, smooth: bool = False) -> None:
+def gen_e2e_outputs(out: str, model_type: str, n_tiles: int, first_tile: int, seed: int = 0, smooth: bool = False, content: int = 1024) -> None:
     """More tiles of the same model, outputs only (logits, boxes, the oracle-derived NMS list): the end-to-end tolerance is
     then checked on several inputs, not on one.  One tile per forward (bounded memory)."""
     enc, dec, pe = build_ref_model(model_type)
@@ -249,6 +249,9 @@ def gen_e2e_outputs(out: str, model_type: str, n_tiles: int, first_tile: int, se
     lg, bx = [], []
     for t in range(n_tiles):
         x = torch.from_numpy(synth.make_batch(first_tile + t, 1, smooth=smooth))
+        if content < 1024:                           # the val pipeline's input: content in the top-left corner, zeros elsewhere (utils/misc.py:50-64)
+            x[:, :, content:, :] = 0
+            x[:, :, :, content:] = 0
         t1 = time.time()
         with torch.no_grad():
             emb = enc(x, O.hfc_fft(x))
@@ -264,6 +267,9 @@ def gen_e2e_outputs(out: str, model_type: str, n_tiles: int, first_tile: int, se
     if smooth:
         name = f"e2e_{model_type}_smooth.npz"
         fx["smooth"] = np.array(1)
+    if content < 1024:
+        name = f"e2e_{model_type}_padded{content}.npz"
+        fx["content"] = np.array(content)
     np.savez_compressed(os.path.join(out, name), **fx)
     print(f"[{model_type}] wrote {name}", sum(v.nbytes for v in fx.values()) // 1024, "KiB kept:", [len(fx[f'pp{t}_nms_index']) for t in range(n_tiles)])
 
@@ -331,6 +337,8 @@ def main() -> None:
         gen_e2e_outputs(a.out, "vit_h", n_tiles=2, first_tile=0, seed=1)
     if a.only in ("all", "vit_h_smooth"):
         gen_e2e_outputs(a.out, "vit_h", n_tiles=2, first_tile=0, smooth=True)
+    if a.only in ("all", "vit_h_padded"):
+        gen_e2e_outputs(a.out, "vit_h", n_tiles=2, first_tile=0, smooth=True, content=768)
 
 
 if __name__ == "__main__":

@@ -495,17 +495,24 @@ def test_vit_h_fp8_batch16_vs_reference_golden(golden_dir):
     assert bool(torch.isfinite(lg).all())
 
 
-@pytest.mark.parametrize("fixture", ["e2e_vit_h_tiles1to4.npz", "e2e_vit_h_smooth.npz"])
+@pytest.mark.parametrize("fixture", ["e2e_vit_h_tiles1to4.npz", "e2e_vit_h_smooth.npz", "e2e_vit_h_padded768.npz"])
 @pytest.mark.parametrize("prec", ["fp16", "bf16", "fp8"])
 def test_vit_h_more_tiles_vs_reference_golden(prec, fixture, golden_dir):
     """The end-to-end tolerance on more ViT-H inputs, each fixture run as one batch: four more noise tiles (1..4) and two
-    tiles with low-frequency content (`synth.make_tile_u8(smooth=True)`: pass-band and stop-band energy for the FFT high-pass).
+    tiles with low-frequency content (`synth.make_tile_u8(smooth=True)`: pass-band and stop-band energy for the FFT high-pass),
+    and the same two with content only in the top-left 768 x 768 and zeros elsewhere, which is what the reference's val pipeline
+    feeds the model (resize to 768, normalise, zero-pad to 1024: dataloader_coco.py:288, utils/misc.py:50-64).
     The fixtures hold the reference modules' logits / boxes and the NMS lists (oracle/gen_golden.py --only vit_h_tiles /
     vit_h_smooth).  Per tile: logits within the bar of the precision and, for the 16-bit modes, the NMS index list identical."""
     fx = np.load(os.path.join(golden_dir, fixture))
     n, first = int(fx["n_tiles"]), int(fx["first_tile"])
     m, _ = _model("vit_h", prec)
-    x = torch.from_numpy(synth.make_batch(first, n, smooth="smooth" in fx.files)).to(G.dev())
+    x = torch.from_numpy(synth.make_batch(first, n, smooth="smooth" in fx.files))
+    if "content" in fx.files:
+        c = int(fx["content"])
+        x[:, :, c:, :] = 0
+        x[:, :, :, c:] = 0
+    x = x.to(G.dev())
     with torch.no_grad():
         out = m.detect(x, torch.tensor([[1024, 1024]] * n))
     lg, bx = out["pred_logits"].cpu().numpy(), out["pred_boxes"].cpu().numpy()
