@@ -373,7 +373,7 @@ def test_vit_h_sensitive_profile_fp16(golden_dir):
     assert all(same)
 
 
-@pytest.mark.parametrize("prec", ["bf16"])
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
 def test_vit_h_batches_golden_tile_and_bit_identity(prec, golden_dir):
     """The configurations bench.py times (BASELINE.json configs[1] B = 4, configs[2] B = 16): tile 0 of the batch is the
     golden tile, checked against the reference-generated fixture; a tile's result is bit-identical whatever its batch
@@ -387,7 +387,7 @@ def test_vit_h_batches_golden_tile_and_bit_identity(prec, golden_dir):
     x16 = torch.from_numpy(synth.make_batch(first, 16)).to(G.dev())
     ts = torch.tensor([[1024, 1024]] * 16)
     outs, variants = {}, {}
-    for B in (16, 4, 1):
+    for B in (16, 5, 4, 1):                                               # 5: an odd batch (80 row tiles: rounds that do not fill)
         xb = x16[:B].contiguous()
         m.detect(NestedTensor(xb, None), ts[:B])                      # weights packed / handle sized before counting
         Nn.gemm_variant_counts(reset=True)
@@ -401,7 +401,7 @@ def test_vit_h_batches_golden_tile_and_bit_identity(prec, golden_dir):
         assert v.get("v5_320_res", 0) >= 2 * depth and v.get("v5_320", 0) >= 2 * depth, v     # proj + lin2, qkv + lin1 of every block
         assert "v2_160" not in v and "v1_128" not in v, v
     assert variants[1].get("v2_160", 0) >= 2 * depth and variants[1].get("v5_320_res", 0) == 0, variants[1]
-    for B in (16, 4, 1):
+    for B in (16, 5, 4, 1):
         lg = outs[B]["pred_logits"][:1].numpy()
         lerr = np.linalg.norm(lg - fx["pred_logits"]) / np.linalg.norm(fx["pred_logits"])
         berr = np.abs(outs[B]["pred_boxes"][:1].numpy() - fx["pred_boxes"]).max()
@@ -410,7 +410,7 @@ def test_vit_h_batches_golden_tile_and_bit_identity(prec, golden_dir):
         assert berr < 5 * LOGIT_TOL[prec], (B, berr)
         rec = split_records(outs[B]["records"])
         assert _nms_positions(rec, 0) == fx["pp0_nms_index"].tolist(), B
-    for B in (4, 1):
+    for B in (5, 4, 1):
         for k in ("pred_logits", "pred_boxes", "records"):
             # records hold int32 fields behind a float32 view (nms_rank = -1 reads as NaN): compare the bits
             assert torch.equal(outs[B][k].view(torch.int32), outs[16][k][:B].view(torch.int32)), (B, k)
