@@ -39,6 +39,27 @@ def test_cvt_matches_torch_rounding(prec):
     assert torch.equal(y.view(torch.int16), want.view(torch.int16))
 
 
+@pytest.mark.parametrize("M,N,K,act", [(4096, 3840, 1280, 0), (4096, 5120, 1280, 1), (128, 128, 64, 0)])
+def test_fp16_outputs_saturate_instead_of_overflowing(M, N, K, act):
+    """fp16 is the default operand type; its range ends at 65504.  A 16-bit GEMM output that exceeds it (here |y| up to ~2e5,
+    through the plain and the GELU epilogue of the block kernels and the small-shape kernel) must come out as +-65504, never
+    inf / NaN, and in-range values must be unaffected."""
+    dev = G.dev()
+    a = G.to16(torch.randn(M, K, device=dev) * 200.0, "fp16")
+    w = G.to16(torch.randn(N, K, device=dev) * 200.0 / math.sqrt(K), "fp16")
+    o32, o16 = G.gemm16(a, w, None, act=act, prec="fp16", want32=True, want16=True)
+    ref = a.float() @ w.float().t()
+    if act == 1:
+        ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))
+    assert bool(torch.isfinite(o16.float()).all())
+    assert (ref.abs() > 65504).sum().item() > 0                       # the case does overflow fp16
+    want = ref.clamp(-65504, 65504)
+    big = ref.abs() > 65504
+    assert bool((o16.float()[big].abs() == 65504).all())
+    assert G.rel_l2(o16.float()[~big], want[~big]) < 2e-3
+    assert G.rel_l2(o32, ref) < 2e-3                                    # the fp32 output of the same launch is not clamped
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 1280), (4096, 3840, 1280), (512, 256, 2304), (8192, 1280, 5120)])
 def test_gemm16_plain(prec, M, N, K):
