@@ -29,7 +29,11 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 1
+/* 2 (round 3): wm_config.fp8_gemms; wm_debug_saturation_*; wm_op_layernorm rejects WM_PREC_FP8 with an fp32 output;
+ * wm_profile_read no longer reports the fused-LayerNorm time-out (wm_forward / wm_encoder_forward do); precision value 2
+ * (fp8), WM_FLAG_MERGED and a NULL handle in wm_postprocess_nms date from round 2.  The Python binding refuses a library
+ * whose wm_abi_version() differs from the value it was written for. */
+#define WM_ABI_VERSION 2
 
 /* operand type of the transformer blocks' MFMA GEMMs / attention (accumulation, residual stream, LayerNorm
  * statistics, softmax and the whole decoder are fp32; the stem, the HFC adaptor and the neck -- 2.9 % of the
@@ -56,9 +60,17 @@ typedef struct wm_config {
     int32_t global_attn_indexes[WM_MAX_GLOBAL];
     int32_t max_batch;                        /* tiles per call the workspace is sized for */
     int32_t precision;                        /* WM_PREC_* */
-    int32_t flags;                            /* WM_FLAG_* engine options, 0 = defaults */
-    int32_t reserved[3];
+    int32_t flags;                            /* WM_CFG_* engine options, 0 = defaults */
+    int32_t fp8_gemms;                        /* WM_PREC_FP8 only: WM_FP8_* mask of the blocks' GEMMs that run e4m3; 0 = default (all) */
+    int32_t reserved[2];
 } wm_config;
+
+/* wm_config.fp8_gemms (also env WM_FP8_GEMMS when the field is 0): which GEMMs of a transformer block use the fp8 MFMA in
+ * WM_PREC_FP8 mode; the others and attention run bf16.  lin1 and lin2 switch together (lin1's epilogue writes lin2's operand). */
+#define WM_FP8_QKV 1
+#define WM_FP8_PROJ 2
+#define WM_FP8_MLP 4
+#define WM_FP8_ALL 7
 
 /* wm_config.flags.  WM_CFG_FUSE_LN: the two residual GEMMs of a transformer block also produce the LayerNorm that
  * follows them (see wm_op_gemm16_ln) where the batch allows; results are bit-identical either way.  Off by default:
@@ -113,7 +125,8 @@ int wm_preprocess_u8(const uint8_t* img_dev, float* out_dev, int batch, int heig
  * any size are resampled to (oh, ow) = wm_resized_size(...) with Pillow's 8-bit bilinear resample arithmetic
  * (antialiased triangle filter, 22-bit fixed-point coefficients, horizontal then vertical pass; bit-exact with
  * PIL.Image.resize, tests/golden/resize_pil.npz), then ToTensor + Normalize + zero padding to 1024 x 1024.  Coefficient
- * tables and the intermediate image are cached by the library per device and geometry.  (oh, ow) must fit the canvas. */
+ * tables are cached by the library per device and geometry, the intermediate image per (device, stream), so calls on
+ * different streams may overlap.  (oh, ow) must fit the canvas. */
 int wm_preprocess_u8_resized(const uint8_t* img_dev, float* out_dev, int batch, int height, int width, int size, int max_size,
                              void* stream);
 /* augmentation.py:80-99 get_size_with_aspect_ratio: the (oh, ow) the resize above produces */
@@ -201,7 +214,7 @@ int wm_profile_read(wm_handle* h, wm_kclass_stat* out /* [WM_KCLASS_COUNT] */);
 #define WM_GEMM_V1_128 0        /* gemm16_kernel 128x128x64 (M % 256 != 0) */
 #define WM_GEMM_V2_160 1        /* gemm16v2_kernel<160>: half-width, few tiles (1-2 image tiles per call) */
 #define WM_GEMM_V2_128 2        /* gemm16v2_kernel<128> */
-#define WM_GEMM_V3_LOCKSTEP 3   /* gemm16v3_kernel (WM_GEMM_MODE=3/4 A/B runs, K = 32) */
+#define WM_GEMM_V3_LOCKSTEP 3   /* (round 1-2 A/B instance, no longer built; id kept) */
 #define WM_GEMM_V3_CONV3X3 4    /* gemm16v3_kernel AMODE 1: implicit-GEMM 3x3 conv (neck) */
 #define WM_GEMM_V5_320 5        /* gemm16v5_kernel<320>, no residual */
 #define WM_GEMM_V5_320_RES 6    /* gemm16v5_kernel<320>, fp32 residual by LDS-DMA (proj / lin2 of ViT-H) */
@@ -214,6 +227,22 @@ int wm_profile_read(wm_handle* h, wm_kclass_stat* out /* [WM_KCLASS_COUNT] */);
 #define WM_GEMM_VARIANT_COUNT 13
 int wm_debug_gemm_variant_counts(int64_t* out /* [WM_GEMM_VARIANT_COUNT] */, int n);
 int wm_debug_reset_gemm_variant_counts(void);
+
+/* ---- saturation census (opt-in; a trained checkpoint with activation outliers) ----------------------------------------
+ * fp16 operands clamp at +-65504 (every fp32 -> fp16 conversion of the path saturates instead of producing inf) and e4m3
+ * operands at +-448.  With the census enabled, every encoder forward counts, after the kernel that produced them, the
+ * elements of the blocks' operand buffers that sit AT the clamp value (or are inf / NaN: bf16): LayerNorm outputs, the
+ * packed qkv, the attention output, the GELU hidden, the 16-bit copy of the last block's output.  A non-zero count
+ * means clamped operands: switch that checkpoint to WM_PREC_BF16 (no clamp, 8-bit mantissa).  Costs one streaming read of
+ * each buffer; off by default and absent from timed runs. */
+#define WM_SAT_LN 0
+#define WM_SAT_QKV 1
+#define WM_SAT_ATTN 2
+#define WM_SAT_HID 3
+#define WM_SAT_LAST 4
+#define WM_SAT_COUNT 5
+int wm_debug_saturation_enable(wm_handle* h, int on);
+int wm_debug_saturation_read(wm_handle* h, int64_t* out /* [WM_SAT_COUNT] */, int n, int reset, void* stream);
 
 /* ---- single-op entry points (kernel-level parity tests) --------------------
  * Thin launches of individual kernels on caller-provided device buffers.

@@ -13,7 +13,13 @@ What the reference cannot produce here (torchvision missing): MedSAM.fft's
 Grayscale and the NMS step.  For those the fixture stores the oracle's own
 output, flagged `pinned=0`.
 
-Usage:  python oracle/gen_golden.py [--only small|vit_b|vit_l|vit_h|vit_h_tiles|vit_h_seed1|vit_h_smooth|vit_h_padded] [--out tests/golden]
+Round 3: `--only postprocess` pins A19.  The reference's PostProcess class (build_sam.py:212-258) and
+box_cxcywh_to_xyxy (utils/box_ops.py:9-13) are torch-only bodies inside modules that import torchvision at the top,
+so they are taken out of the reference's files with `ast` (the class / function definition nodes, compiled and
+executed here, nothing stored) and run on the logits / boxes the end-to-end fixtures already hold plus edge cases;
+outputs go to postprocess_ref.npz with pinned=1.  NMS (torchvision.ops.nms) and Grayscale stay unpinned.
+
+Usage:  python oracle/gen_golden.py [--only small|postprocess|vit_b|vit_l|vit_h|vit_h_tiles|vit_h_seed1|vit_h_smooth|vit_h_padded|vit_h_outlier] [--out tests/golden]
 """
 from __future__ import annotations
 
@@ -274,6 +280,69 @@ def gen_e2e_outputs(out: str, model_type: str, n_tiles: int, first_tile: int, se
     print(f"[{model_type}] wrote {name}", sum(v.nbytes for v in fx.values()) // 1024, "KiB kept:", [len(fx[f'pp{t}_nms_index']) for t in range(n_tiles)])
 
 
+def ref_postprocess():
+    """The reference's own PostProcess + box_cxcywh_to_xyxy, extracted by definition node (no stand-in modules)."""
+    import ast
+    import types
+    import torch.nn.functional as F
+    from torch import nn
+
+    def node_src(path, kind, name):
+        with open(path) as f:
+            src = f.read()
+        for n in ast.parse(src).body:
+            if isinstance(n, kind) and n.name == name:
+                return ast.get_source_segment(src, n)
+        raise KeyError(name)
+
+    ns_box = {"torch": torch}
+    exec(compile(node_src(os.path.join(REF, "utils", "box_ops.py"), ast.FunctionDef, "box_cxcywh_to_xyxy"), "box_ops.py", "exec"), ns_box)
+    ns = {"torch": torch, "F": F, "nn": nn, "box_ops": types.SimpleNamespace(box_cxcywh_to_xyxy=ns_box["box_cxcywh_to_xyxy"])}
+    exec(compile(node_src(os.path.join(REF, "build_sam.py"), ast.ClassDef, "PostProcess"), "build_sam.py", "exec"), ns)
+    return ns["PostProcess"], ns_box["box_cxcywh_to_xyxy"]
+
+
+def gen_postprocess(out: str) -> None:
+    """A19 pinned: reference PostProcess outputs on (a) the logits / boxes of every committed end-to-end fixture, (b) seeded
+    random heads with non-square target sizes, (c) a tile with nothing above the confidence threshold."""
+    PP, cxcywh = ref_postprocess()
+    pp = PP(confidence_threshold=0.05).eval()
+    fx = {"pinned": np.array(1)}
+    cases = []
+    gold = out
+    for name in ("e2e_vit_b.npz", "e2e_vit_l.npz", "e2e_vit_h.npz", "e2e_vit_h_tiles1to4.npz", "e2e_vit_h_seed1.npz"):
+        d = np.load(os.path.join(gold, name))
+        lg, bx = torch.from_numpy(d["pred_logits"]), torch.from_numpy(d["pred_boxes"])
+        cases.append((name[:-4], lg, bx, torch.tensor([[1024, 1024]] * lg.shape[0])))
+    g = torch.Generator().manual_seed(19)
+    lg = torch.randn(3, 51, 7, generator=g) * 3
+    bx = torch.rand(3, 51, 4, generator=g)
+    cases.append(("random", lg, bx, torch.tensor([[640, 480], [1024, 768], [333, 1000]])))
+    lg0 = torch.zeros(1, 51, 7)
+    lg0[..., -1] = 12.0                                     # background wins everywhere: nothing above 0.05
+    cases.append(("empty", lg0, torch.rand(1, 51, 4, generator=g), torch.tensor([[1024, 1024]])))
+    fx["cases"] = np.array([c[0] for c in cases])
+    for tag, lg, bx, ts in cases:
+        with torch.no_grad():
+            res = pp({"pred_logits": lg, "pred_boxes": bx}, ts)
+        fx[f"{tag}_logits"], fx[f"{tag}_boxes"], fx[f"{tag}_sizes"] = lg.numpy(), bx.numpy(), ts.numpy()
+        for b, r in enumerate(res):
+            fx[f"{tag}_pp{b}_scores"] = r["scores"].to(torch.float32).numpy()
+            fx[f"{tag}_pp{b}_labels"] = r["labels"].to(torch.int64).numpy()
+            fx[f"{tag}_pp{b}_boxes"] = r["boxes"].to(torch.float32).numpy().reshape(-1, 4)
+        # the oracle restatement must agree bit for bit before the fixture is written
+        mine = O.postprocess(lg, bx, ts)
+        for b, r in enumerate(res):
+            assert torch.equal(mine[b]["scores"], r["scores"].to(torch.float32)), (tag, b)
+            assert torch.equal(mine[b]["labels"], r["labels"].to(torch.int64)), (tag, b)
+            assert torch.equal(mine[b]["boxes"].reshape(-1, 4), r["boxes"].to(torch.float32).reshape(-1, 4)), (tag, b)
+    x = torch.rand(5, 9, 4, generator=g)
+    fx["cxcywh_in"], fx["cxcywh_out"] = x.numpy(), cxcywh(x).numpy()
+    np.savez_compressed(os.path.join(out, "postprocess_ref.npz"), **fx)
+    print("wrote postprocess_ref.npz", sum(v.nbytes for v in fx.values()) // 1024, "KiB; cases:", [c[0] for c in cases],
+          "(oracle restatement bit-identical on all)")
+
+
 def gen_coco_subset(out: str, n_images: int = 8) -> None:
     """Data fixture for the COCO bbox evaluator: the first images of the reference's own annotation file
     (coco_annotations/val.json: 6 categories, xywh boxes, area, iscrowd) with their annotations, verbatim."""
@@ -323,6 +392,8 @@ def main() -> None:
         gen_small(a.out)
     if a.only in ("all", "resize"):
         gen_resize(a.out)
+    if a.only in ("postprocess",):                # after the end-to-end fixtures exist (reads their logits / boxes)
+        gen_postprocess(a.out)
     if a.only in ("all", "coco"):
         gen_coco_subset(a.out)
     if a.only in ("all", "vit_b"):

@@ -8,7 +8,9 @@ fail loudly when the HIP library is missing.
 
 Parity status: PINNED for everything that torch provides (encoder, HFC
 adaptor, decoder, heads, FFT) by golden vectors generated here from the
-reference's own `modeling` modules (oracle/gen_golden.py -> tests/golden/).
+reference's own `modeling` modules (oracle/gen_golden.py -> tests/golden/),
+and (round 3) for PostProcess / box_cxcywh_to_xyxy by running the reference's own class / function bodies, taken from
+build_sam.py:212-258 and utils/box_ops.py:9-13 by definition node (tests/golden/postprocess_ref.npz, bit-exact).
 UNPINNED for the two torchvision functions on the path, because torchvision is
 not installed in this image: `Grayscale` (network.py:41) and `ops.nms`
 (visualize_prediction.py:154).  Those two are restated from their published
@@ -432,7 +434,7 @@ def model_forward(x: Tensor, W: Dict[str, Tensor], cfg: OracleCfg,
 
 
 # ----------------------------------------------------------------------------
-# A19  PostProcess  (build_sam.py:219-258, utils/box_ops.py:9-13)
+# A19  PostProcess  (build_sam.py:219-258, utils/box_ops.py:9-13)   PINNED: tests/golden/postprocess_ref.npz
 # ----------------------------------------------------------------------------
 def postprocess(logits: Tensor, boxes: Tensor, target_sizes: Tensor, thr: float = 0.05) -> List[Dict[str, Tensor]]:
     prob = logits.softmax(-1)

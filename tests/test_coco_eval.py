@@ -135,3 +135,26 @@ def test_coco12_agrees_with_bbox_map_on_reference_annotation_data(golden_dir):
     assert np.allclose(ce.coco_eval["bbox"].stats, s)
     with pytest.raises(NotImplementedError):
         CocoEvaluator(ds, ("bbox", "segm"))
+
+
+def test_coco12_crowd_area_split_and_ignore_field_hand_worked():
+    """One image, one category, worked on paper.  Ground truth: A small 20x20; B medium 50x50; C large
+    200x200 with iscrowd = 1; D medium 40x40 carrying ignore = 1 but iscrowd = 0 -- the published COCOeval overwrites
+    `ignore` with `iscrowd`, so D IS a target (and is missed).  Detections: .9 = A exactly, .8 inside the crowd (absorbed),
+    .7 = B exactly, .6 a small false positive.
+      all:    targets A, B, D; TP, (ignored), TP, FP -> recall 1/3, 2/3 at precision 1 -> 67 of 101 recall points
+      small:  target A; the B match and the crowd match are ignored, the small FP counts but ranks after the TP -> AP 1
+      medium: targets B, D; the A match, the crowd match and the out-of-range FP are ignored -> recall 1/2 -> 51 / 101
+      large:  only the crowd -> no target -> -1."""
+    anns = [(1, (0, 0, 20, 20), 0, 0), (2, (100, 100, 50, 50), 0, 0), (3, (300, 300, 200, 200), 1, 0), (4, (600, 600, 40, 40), 0, 1)]
+    ds = {"images": [], "categories": [{"id": 1}],
+          "annotations": [{"id": i, "image_id": 1, "category_id": 1, "bbox": list(b), "area": b[2] * b[3], "iscrowd": c, "ignore": ig}
+                          for i, b, c, ig in anns]}
+    dets = {1: _d([[0, 0, 20, 20], [320, 320, 360, 360], [100, 100, 150, 150], [800, 800, 830, 830]], [0.9, 0.8, 0.7, 0.6], [1, 1, 1, 1])}
+    s = _run(ds, dets)
+    assert s[0] == pytest.approx(67 / 101, abs=1e-12) and s[1] == pytest.approx(67 / 101, abs=1e-12) and s[2] == pytest.approx(67 / 101, abs=1e-12)
+    assert s[3] == pytest.approx(1.0, abs=1e-12)
+    assert s[4] == pytest.approx(51 / 101, abs=1e-12)
+    assert s[5] == -1
+    assert s[6] == pytest.approx(1 / 3, abs=1e-12) and s[7] == pytest.approx(2 / 3, abs=1e-12) and s[8] == pytest.approx(2 / 3, abs=1e-12)
+    assert s[9] == pytest.approx(1.0, abs=1e-12) and s[10] == pytest.approx(0.5, abs=1e-12) and s[11] == -1

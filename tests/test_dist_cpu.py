@@ -148,4 +148,40 @@ def test_evaluate_two_ranks_matches_single_process():
     for rank, stats, img_ids in got:
         assert stats["coco_eval_bbox"] == pytest.approx(single["coco_eval_bbox"], abs=1e-12), rank
         assert img_ids == sorted(ev.img_ids)
-        assert stats["images"] == 9                                  # 8 + the duplicate, summed over ranks as processed
+        assert stats["images"] == 8 == single["images"]              # the duplicate image (sampler padding) is counted once
+        assert stats["detections"] == single["detections"]
+
+
+def _bad_worker(rank, world, port, q):
+    """Rank 1 holds an image with 52 detections (more than a record's 51 slots): BOTH ranks must raise, none may be left
+    waiting inside a collective; a third, huge image id checks the int64 id packing."""
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mk = lambda n: {"boxes": np.zeros((n, 4), np.float32), "scores": np.linspace(0.1, 0.9, n).astype(np.float32), "labels": np.arange(n) % 6}
+    good = {(1 << 40) + rank: mk(3 + rank), 7: mk(2)}                      # image 7 is on both ranks
+    merged = wdist.gather_detections(good)
+    ok = sorted(merged) == [7, (1 << 40), (1 << 40) + 1] and len(merged[(1 << 40) + 1]["scores"]) == 4 and merged[7]["labels"].tolist() == [0, 1]
+    raised = ""
+    try:
+        wdist.gather_detections({rank: mk(52 if rank == 1 else 5)})
+    except ValueError as e:
+        raised = str(e)
+    dist.barrier()                                                          # both ranks are still in step
+    q.put((rank, ok, raised))
+    dist.destroy_process_group()
+
+
+def test_gather_detections_error_is_collective_and_ids_are_int64():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in got), got
+    assert "52 detections" in got[1][2] and "another rank" in got[0][2], got

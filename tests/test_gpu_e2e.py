@@ -118,6 +118,26 @@ def test_postprocess_nms_random_and_edges():
     assert len(post({"pred_logits": logits.to(G.dev()), "pred_boxes": boxes.to(G.dev())}, ts.to(G.dev()))[1]["scores"]) == 0
 
 
+def test_postprocess_vs_reference_fixture(golden_dir):
+    """A19 against the reference's OWN PostProcess outputs (tests/golden/postprocess_ref.npz, pinned=1: the class body of
+    build_sam.py:212-258 run by oracle/gen_golden.py --only postprocess): postprocess_nms_kernel's scores / labels / scaled
+    boxes on every case of the fixture, including non-square target sizes and the empty result."""
+    _, post = _model("vit_b", "fp16")
+    fx = np.load(os.path.join(golden_dir, "postprocess_ref.npz"))
+    assert int(fx["pinned"]) == 1
+    dev = G.dev()
+    for tag in fx["cases"]:
+        tag = str(tag)
+        lg, bx, ts = (torch.from_numpy(fx[f"{tag}_{k}"]) for k in ("logits", "boxes", "sizes"))
+        got = post({"pred_logits": lg.to(dev), "pred_boxes": bx.to(dev)}, ts.to(dev))
+        for b, g in enumerate(got):
+            want_s, want_l, want_b = fx[f"{tag}_pp{b}_scores"], fx[f"{tag}_pp{b}_labels"], fx[f"{tag}_pp{b}_boxes"]
+            assert g["scores"].shape[0] == want_s.shape[0], (tag, b)
+            np.testing.assert_allclose(g["scores"].cpu().numpy(), want_s, rtol=2e-6, atol=1e-7)
+            np.testing.assert_array_equal(g["labels"].cpu().numpy(), want_l)
+            np.testing.assert_allclose(g["boxes"].cpu().numpy().reshape(-1, 4), want_b, rtol=1e-6, atol=1e-4)
+
+
 # ---------------------------------------------------------------------------
 # full model vs golden fixtures
 # ---------------------------------------------------------------------------
@@ -485,6 +505,59 @@ def test_vit_b_fp8_vs_reference_golden_and_emulation(golden_dir):
     err = G.rel_l2(out["pred_logits"][:1], ref["pred_logits"])
     print(f"[vit_b/fp8] GPU vs CPU emulation of the fp8 arithmetic: logits={err:.2e}")
     assert err < 5e-3, err
+
+
+def test_fp8_gemm_mask_and_saturation_census(golden_dir):
+    """wm_config.fp8_gemms (round 3): ViT-B with only the MLP pair on the fp8 MFMA (qkv / proj / attention bf16).  The GEMM
+    instance counters show the mix; its logits error lies between bf16's and all-fp8's.  Then the saturation census
+    (wm_debug_saturation_*): zero on the synthetic weights in fp16 mode; a lin1 bias pushed past fp16's range makes the GELU
+    hidden clamp at 65504 and the census reports it (the signal for switching such a checkpoint to bf16)."""
+    from wildlifemapper_amd import _native as Nn
+    fx = np.load(os.path.join(golden_dir, "e2e_vit_b.npz"))
+    m, _ = _model("vit_b", "fp8")
+    hub = m._hub
+    x = torch.from_numpy(synth.make_batch(0, 2)).to(G.dev())
+    ts = torch.tensor([[1024, 1024]] * 2)
+    errs = {}
+    try:
+        for name, mask in (("all", Nn.FP8_ALL), ("mlp", Nn.FP8_MLP), ("qkv+proj", Nn.FP8_QKV | Nn.FP8_PROJ)):
+            hub.set_fp8_gemms(mask)
+            m.detect(NestedTensor(x, None), ts)
+            Nn.gemm_variant_counts(reset=True)
+            out = m.detect(NestedTensor(x, None), ts)
+            torch.cuda.synchronize()
+            var = {k: v for k, v in Nn.gemm_variant_counts().items() if v}
+            n8 = {"all": 4, "mlp": 2, "qkv+proj": 2}[name] * 12
+            assert var.get("fp8_256", 0) == n8, (name, var)
+            lg = out["pred_logits"].cpu().numpy()
+            errs[name] = float(np.linalg.norm(lg - fx["pred_logits"]) / np.linalg.norm(fx["pred_logits"]))
+    finally:
+        hub.set_fp8_gemms(0)
+    print(f"[vit_b/fp8 masks] logits rel-L2 vs reference: {errs}")
+    assert errs["mlp"] < errs["all"] and errs["qkv+proj"] < errs["all"] and errs["all"] < FP8_LOGIT_TOL
+    # --- saturation census, fp16 mode
+    m, _ = _model("vit_b", "fp16")
+    hub = m._hub
+    m.detect(NestedTensor(x, None), ts)
+    hub.saturation_enable(True)
+    try:
+        hub.saturation_read(reset=True)
+        m.detect(NestedTensor(x, None), ts)
+        clean = hub.saturation_read(reset=True)
+        assert set(clean) == set(Nn.SAT_NAMES) and all(v == 0 for v in clean.values()), clean
+        bias = m.image_encoder.blocks[5].mlp.lin1.bias
+        keep = bias.detach().clone()
+        with torch.no_grad():
+            bias[:7] += 1.0e5                          # GELU(1e5) = 1e5 > 65504: seven hidden channels clamp on every token
+        m.detect(NestedTensor(x, None), ts)
+        hot = hub.saturation_read(reset=True)
+        with torch.no_grad():
+            bias.copy_(keep)
+        assert hot["mlp_hidden"] == 7 * 2 * 4096, hot
+        m.detect(NestedTensor(x, None), ts)
+        assert all(v == 0 for v in hub.saturation_read().values())
+    finally:
+        hub.saturation_enable(False)
 
 
 def test_vit_h_fp8_batch16_vs_reference_golden(golden_dir):

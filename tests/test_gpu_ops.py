@@ -195,22 +195,6 @@ def test_gemm16_dispatch_and_values_at_model_shapes(M, N, K, act, variant):
     assert G.rel_l2(o16.float(), y) < OUT16_TOL[prec]
 
 
-@pytest.mark.parametrize("M,N,K,act", [(32768, 3840, 1280, 0), (32768, 5120, 1280, 1), (32768, 3072, 1024, 0)])
-def test_gemm16_persistent_instance_bit_identical(M, N, K, act, monkeypatch):
-    """The opt-in persistent instance (WM_GEMM_PERSIST=1: one workgroup per CU walks the tiles, next tile's first K-steps
-    requested during the epilogue; measured slower, kept off) computes the same bits as the default kernel."""
-    prec, dev = "bf16", G.dev()
-    a = G.to16(torch.randn(M, K, device=dev), prec)
-    w = G.to16(torch.randn(N, K, device=dev) / math.sqrt(K), prec)
-    bias = torch.randn(N, device=dev)
-    monkeypatch.setenv("WM_GEMM_PERSIST", "0")
-    _, base = G.gemm16(a, w, bias, None, 0, act, prec, want32=False, want16=True)
-    monkeypatch.setenv("WM_GEMM_PERSIST", "1")
-    for _ in range(3):
-        _, pers = G.gemm16(a, w, bias, None, 0, act, prec, want32=False, want16=True)
-        assert torch.equal(base, pers)
-
-
 def test_gemm16_kernels_agree_bitwise():
     """A tile's result must not depend on which GEMM kernel its batch size selects (batch-invariant
     bit for bit): the same rows through the half-width kernel (M = 4096) and through the staggered 256 x 320 kernel
@@ -364,12 +348,9 @@ def _ref_encoder_attention(qkv, bias16, rel_h, rel_w, B, heads, hd, window, prec
     return o.reshape(B * 4096, D)
 
 
-@pytest.mark.parametrize("kernel", ["1", "2"])
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("heads,hd", [(2, 80), (3, 64)])
-def test_window_attention(prec, heads, hd, kernel, monkeypatch):
-    # kernel 1 = the default; 2 = the opt-in LDS-DMA / exact-softmax kernel (attn_win2.h, WM_ATTN_WIN=2, read per launch)
-    monkeypatch.setenv("WM_ATTN_WIN", kernel)
+def test_window_attention(prec, heads, hd):
     B, D = 2, heads * hd
     dev = G.dev()
     qkv = G.to16(torch.randn(B * 4096, 3 * D, device=dev), prec)
@@ -382,12 +363,9 @@ def test_window_attention(prec, heads, hd, kernel, monkeypatch):
     assert (out.float() - ref).abs().max().item() < (0.06 if prec == "bf16" else 0.01)
 
 
-@pytest.mark.parametrize("kernel", ["1", "2"])
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("heads,hd", [(2, 80), (2, 64)])
-def test_global_attention_relpos(prec, heads, hd, kernel, monkeypatch):
-    # kernel 1 = the default; 2 = the opt-in two-blocks-per-wave kernel (attn_glob2.h, WM_ATTN_GLOBAL=2, read per launch)
-    monkeypatch.setenv("WM_ATTN_GLOBAL", kernel)
+def test_global_attention_relpos(prec, heads, hd):
     B, D = 1, heads * hd
     dev = G.dev()
     qkv = G.to16(torch.randn(B * 4096, 3 * D, device=dev), prec)
@@ -399,11 +377,9 @@ def test_global_attention_relpos(prec, heads, hd, kernel, monkeypatch):
     assert G.rel_l2(out.float(), ref) < 2 * OUT16_TOL[prec]
 
 
-@pytest.mark.parametrize("kernel", ["1", "2"])
-def test_global_attention_forces_rescale(kernel, monkeypatch):
+def test_global_attention_forces_rescale():
     """One key row spiked against the queries so the running max jumps at a late tile (online-softmax
-    rescale branch; cdna guide rule 26).  Both global kernels (WM_ATTN_GLOBAL, read per launch)."""
-    monkeypatch.setenv("WM_ATTN_GLOBAL", kernel)
+    rescale branch; cdna guide rule 26)."""
     heads, hd, prec, dev = 1, 80, "bf16", G.dev()
     D = heads * hd
     x = torch.randn(4096, 3 * D, device=dev) * 0.3
@@ -515,25 +491,6 @@ def test_gemm8_16bit_and_fp8_outputs(M, N, K, act):
     mism = (got != want8).float().mean().item()
     assert mism < 2e-3, mism                              # ties / fp32 summation-order differences at rounding boundaries only
     assert G.rel_l2(got, y) < 0.04
-
-
-def test_gemm8_k64_variant_matches_default(monkeypatch):
-    """The 64-byte-K-step variant (4-slot ring, DMA pieces between the MFMAs; WM_GEMM8_BK=64) computes the same bits as
-    the default 128-byte one: both accumulate the 64-deep MFMA steps in the same order."""
-    dev = G.dev()
-    M, N, K = 1024, 768, 1280
-    a8 = G.to_fp8(torch.randn(M, K, device=dev))
-    w8, sc = G.quant_weight_fp8(torch.randn(N, K, device=dev) / math.sqrt(K))
-    bias = torch.randn(N, device=dev)
-    res = torch.randn(M, N, device=dev)
-    outs = {}
-    for bk in ("128", "64"):
-        monkeypatch.setenv("WM_GEMM8_BK", bk)
-        outs[bk] = (G.gemm8(a8, w8, sc, bias, res, 0, "f32"), G.gemm8(a8, w8, sc, bias, None, 1, "8"), G.gemm8(a8, w8, sc, bias, None, 0, "16"))
-    for x, y in zip(outs["128"], outs["64"]):
-        assert torch.equal(x, y)
-    want = res + (G.from_fp8(a8) @ G.from_fp8(w8).t()) * sc + bias
-    assert G.rel_l2(outs["64"][0], want) < 1e-5
 
 
 def test_gemm8_rejects_bad_shapes():

@@ -206,3 +206,28 @@ def test_pil_resize_restatement(golden_dir):
     assert R.get_size_with_aspect_ratio((6000, 4000), 768, 768) == (512, 768)
     assert R.get_size_with_aspect_ratio((3648, 5472), 768, 768) == (768, 512)
     assert R.get_size_with_aspect_ratio((1000, 1000), 768, 768) == (768, 768)
+
+
+def test_postprocess_restatement_vs_reference_fixture(golden_dir):
+    """A19 pinned (round 3): oracle.postprocess against tests/golden/postprocess_ref.npz, which oracle/gen_golden.py
+    --only postprocess produced by running the reference's own PostProcess class (build_sam.py:212-258) and
+    box_cxcywh_to_xyxy (utils/box_ops.py:9-13), taken from the reference files by definition node, on the logits / boxes of
+    the end-to-end fixtures, on random heads with non-square target sizes and on a tile with nothing above the confidence
+    threshold.  Bit-exact: same torch ops in the same order."""
+    fx = np.load(os.path.join(golden_dir, "postprocess_ref.npz"))
+    assert int(fx["pinned"]) == 1
+    for tag in fx["cases"]:
+        tag = str(tag)
+        lg, bx, ts = (torch.from_numpy(fx[f"{tag}_{k}"]) for k in ("logits", "boxes", "sizes"))
+        got = O.postprocess(lg, bx, ts)
+        for b, r in enumerate(got):
+            assert np.array_equal(r["scores"].numpy(), fx[f"{tag}_pp{b}_scores"]), (tag, b)
+            assert np.array_equal(r["labels"].numpy(), fx[f"{tag}_pp{b}_labels"]), (tag, b)
+            assert np.array_equal(r["boxes"].numpy().reshape(-1, 4), fx[f"{tag}_pp{b}_boxes"]), (tag, b)
+    assert len(fx["empty_pp0_scores"]) == 0 and fx["empty_pp0_boxes"].shape == (0, 4)
+    x = torch.from_numpy(fx["cxcywh_in"])
+    cx, cy, w, h = x.unbind(-1)
+    assert np.array_equal(torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1).numpy(), fx["cxcywh_out"])
+    # the pp*_ keys inside the end-to-end fixtures (written by the oracle, pinned=0 there) equal the reference's outputs
+    e = np.load(os.path.join(golden_dir, "e2e_vit_h.npz"))
+    assert np.array_equal(e["pp0_scores"], fx["e2e_vit_h_pp0_scores"]) and np.array_equal(e["pp0_boxes"], fx["e2e_vit_h_pp0_boxes"])

@@ -34,11 +34,17 @@ namespace wm {
 // K-steps 8..17, every workgroup its wall-clock entry / first barrier / loop end / stores-acknowledged stamps, into
 // p.zero_page.  The instrumented instance is a separate kernel; the product instance carries none of it.
 // LNF: the fp32-residual epilogue also LayerNorms the finished rows (see its code and Gemm16Args::ln_*).
-// (A persistent instance -- one workgroup per CU walking its tiles and prefetching the next tile's first K-steps during the
-// epilogue -- was built in round 2, bit-identical and 7-15 % slower: tools/experiments/gemm16_v5_persist.h)
-template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false>
+// PERSIST (round 2): one workgroup per CU walks the tiles tile = blockIdx.x + i * gridDim.x (gridDim.x a multiple of 8, so a
+// workgroup's tiles keep its XCD's id range of the grouped order) and requests the NEXT tile's first K-steps into the
+// ring while it runs the current tile's epilogue in the LDS above them: the workgroup hand-over on a CU (0.6-1.6 us) and
+// the ring fill (1.7-3.3 us until the first barrier) measured with the DBG timeline no longer sit in front of every 37-44 us
+// K loop.  LDS map with PERSIST (160 KiB): 16-bit / fp32 outputs stage in [2 STAGE, ...) and steps 0, 1 of the next tile
+// land in slots 0, 1; the fp32 + residual epilogue needs 121 KiB (staging + two landing buffers) and lives in [STAGE, ...),
+// so only step 0 is requested ahead (slot 0) and step 1 follows when the next tile starts.
+template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     using C = G3<BN, 4>;
+    static_assert(!PERSIST || (!DBG && !LNF && NSLOT == 3), "the persistent instance is the plain product kernel");
     constexpr int AHEAD = NSLOT - 1;                       // K-steps of DMA in flight
     // timing experiments of tools/gemm_bench.py (--act 256 / 512 / 1024): compiled in only with -DWM_GEMM_TIMING_BITS=1
     constexpr bool TB = WM_GEMM_TIMING_BITS != 0;
@@ -68,7 +74,9 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         tn0 = (in_group / gsz) * BN;
     };
     int m0, n0;
-    tile_origin(blockIdx.x, m0, n0);
+    int tile = blockIdx.x;
+    tile_origin(tile, m0, n0);
+    int pre_issued = 0;                                    // PERSIST: K-steps of the current tile already requested
 
     const unsigned lane_off = (unsigned)(lane >> 2) * (unsigned)(K * 2) + (unsigned)((((lane & 3) ^ ((0 - (lane >> 4)) & 3))) << 4);
     const size_t row_bytes = (size_t)K * 2;
@@ -109,7 +117,16 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
 
     auto read_frags = [&](int slot) {
         const char* sS = smem + slot * C::STAGE;
-        const int rd_a = rd_a_k, rd_w = rd_w_k;
+        int rd_a = rd_a_k, rd_w = rd_w_k;
+        if constexpr (PERSIST) {
+            // recomputed from v_mbcnt every K-step (8 VALU): kept across the tile loop, hipcc spills these two offsets (or the
+            // lane id they derive from) and reloads them here behind a vmcnt(0), which drains the DMA ring every step
+            const int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // lane id from EXEC: no live register
+            const int fr_k = l & 15, fq_k = l >> 4;
+            const int fo = fr_k * 64 + ((fq_k ^ ((0 - (fr_k >> 2)) & 3)) << 4);
+            rd_a = (wr * 128) * 64 + fo;
+            rd_w = C::A_BYTES + (wc * C::WCOLS) * 64 + fo;
+        }
         af[0] = *(const typename T::vec8*)(sS + rd_a);
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) wf[i] = *(const typename T::vec8*)(sS + rd_w + i * 1024);
@@ -125,11 +142,20 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     auto inc = [](int v) { return v == NSLOT - 1 ? 0 : v + 1; };
     auto dec = [](int v) { return v == 0 ? NSLOT - 1 : v - 1; };
     constexpr int RP_CPR = BN * 4 / 16, RP_PW = RP_CPR / 16;       // residual tile: 16-byte chunks per row; DMA pieces per wave and pass
+    // PERSIST_16: the persistent instance that is built serves the 16-bit-output GEMMs only (qkv, lin1: no residual, no fp32
+    // output): with the residual epilogue's address arithmetic also in the tile loop the kernel spills (accumulators included)
+    constexpr bool PERSIST_16 = PERSIST;
+    const bool res_late = PERSIST && !PERSIST_16 && p.residual != nullptr;    // pass 0 of the residual is requested AFTER the first K-steps
     auto wait_step = [&](int s, auto extra_tag) {          // this wave's pieces of step s have landed
         constexpr int P = C::P_LO + (decltype(extra_tag)::value ? 1 : 0);
         if (dbg_noissue) { wait_vmcnt<0>(); return; }
         if constexpr (AHEAD == 3) {
             if (s + 2 < ns) { wait_vmcnt<2 * P>(); return; }
+        }
+        if constexpr (PERSIST) {
+            // steps 0 and 1 of a tile: the residual's pass-0 pieces sit between stage(1) and stage(2) in issue order and may
+            // stay in flight (vmcnt leaves the N youngest operations: stage(s + 1) and those RP_PW pieces)
+            if (res_late && s < 2 && s + 1 < ns) { wait_vmcnt<P + RP_PW>(); return; }
         }
         if (s + 1 < ns) wait_vmcnt<P>(); else wait_vmcnt<0>();
     };
@@ -149,13 +175,13 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     // fp32 residual (proj / lin2: out = residual + A W^T + b): the residual tile comes in by LDS-DMA, 32 rows (16 per
     // wave group) per epilogue pass, one pass ahead; pass 0 is requested at the start of the tile and lands beside the ring.
     constexpr int RES_BYTES = 32 * BN * 4;
-    constexpr int EPI_BASE = 0;                                                   // staging of the 16-bit / fp32 epilogues
-    constexpr int RES_STG = 0;                                                    // staging of the residual epilogue
-    constexpr int RES_L1 = 45056;
-    constexpr int RES_L0 = NSLOT * C::STAGE;
-    constexpr int LDS_TOTAL = NSLOT * C::STAGE + RES_BYTES;
+    constexpr int EPI_BASE = PERSIST ? 2 * C::STAGE : 0;                          // staging of the 16-bit / fp32 epilogues
+    constexpr int RES_STG = PERSIST ? C::STAGE : 0;                               // staging of the residual epilogue
+    constexpr int RES_L1 = PERSIST ? RES_STG + 32 * (BN * 4 + 16) : 45056;
+    constexpr int RES_L0 = PERSIST ? RES_L1 + RES_BYTES : NSLOT * C::STAGE;
+    constexpr int LDS_TOTAL = PERSIST ? 160 * 1024 : NSLOT * C::STAGE + RES_BYTES;
     static_assert(RES_STG + 32 * (BN * 4 + 16) <= RES_L1 && RES_L0 >= NSLOT * C::STAGE && RES_L0 + RES_BYTES <= LDS_TOTAL &&
-                  RES_L1 + RES_BYTES <= NSLOT * C::STAGE && RES_L1 % 16 == 0 && RES_L0 % 16 == 0,
+                  (PERSIST ? RES_L1 + RES_BYTES <= RES_L0 : RES_L1 + RES_BYTES <= NSLOT * C::STAGE) && RES_L1 % 16 == 0 && RES_L0 % 16 == 0,
                   "epilogue LDS map");
     const int res_mod = p.res_mod > 0 ? p.res_mod : p.M;
     const bool res_wrap = res_mod != p.M;                           // broadcast residual (pos_embed): row m % res_mod
@@ -171,17 +197,19 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         }
     };
 
+    for (;;) {                                              // tiles of this workgroup (one iteration unless PERSIST)
 #pragma unroll
     for (int i = 0; i < C::MT; ++i)
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.residual) res_dma(0);
+    if constexpr (!PERSIST_16) { if (!res_late && p.residual) res_dma(0); }
 
     if (wr == 0) {
         using EX = std::integral_constant<bool, (C::W_REM > 0)>;
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i)
-            if (i < ns) stage(i, i, EX{});
+            if (i >= pre_issued && i < ns) stage(i, i, EX{});
+        if (res_late) res_dma(0);
         int slot = 0;
 #pragma unroll 1
         for (int s = 0; s < ns; ++s) {
@@ -204,7 +232,8 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         using EX = std::false_type;
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i)
-            if (i < ns) stage(i, i, EX{});
+            if (i >= pre_issued && i < ns) stage(i, i, EX{});
+        if (res_late) res_dma(0);
         int slot = 0;
 #pragma unroll 1
         for (int s = 0; s < ns; ++s) {
@@ -238,7 +267,12 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     // 128 rows (16-bit output) or 64 rows (fp32 output), each thread then moves 16-byte chunks that are consecutive
     // along the row, and the residual is read the same way.
     const int act = p.act & 0xff;
-    const int tid_e = tid, fr_e = fr, fq_e = fq;
+    // PERSIST: the epilogue's per-lane offsets are derived from an opaque copy of the thread id, so that the compiler
+    // recomputes them per tile instead of hoisting them out of the tile loop and spilling them around the K loop
+    // (cdna_hip_programming.md, persistent-structure pitfalls)
+    int tid_e = tid;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid_e));
+    const int fr_e = tid_e & 15, fq_e = (tid_e & 63) >> 4;
     f32x4 bias_v[C::NT];
 #pragma unroll
     for (int ni = 0; ni < C::NT; ++ni)
@@ -246,6 +280,29 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): this wave's fragment reads are back
     barrier();                                              // every wave is done with the ring
     if constexpr (DBG) we[0] = wall_clock64();
+    // PERSIST: the next tile's first K-steps go into the (now idle) low ring slots while this tile's epilogue runs above them
+    int next_tile = 0, nm0 = 0, nn0 = 0, next_issued = 0;
+    bool has_next = false;
+    auto prefetch_next = [&](int steps) {                   // every wave issues its own pieces, as in the K loop
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (i < steps && i < ns) {
+                if (wr == 0) stage_at(i, i, std::integral_constant<bool, (C::W_REM > 0)>{}, nm0, nn0);
+                else stage_at(i, i, std::false_type{}, nm0, nn0);
+            }
+    };
+    if constexpr (PERSIST) {
+        // the bias values are ordinary loads: make the compiler wait for them HERE (nothing else is in flight), not at their
+        // first use behind the prefetch, where hipcc would drain every outstanding LDS-DMA with vmcnt(0)
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni) asm volatile("" ::"v"(bias_v[ni]));
+        next_tile = tile + (int)gridDim.x;
+        has_next = next_tile < total_tiles;
+        if (has_next) {
+            tile_origin(next_tile, nm0, nn0);
+            if (PERSIST_16 || p.residual == nullptr) { prefetch_next(2); next_issued = 2; }   // residual path: one step, after its pass 0 (below)
+        }
+    }
     // one straight-line instance per activation (a per-fragment runtime branch costs more than the stores)
     auto epilogue = [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
@@ -368,11 +425,14 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             rec[0] = lt1; rec[1] = lt2; rec[2] = lt3; rec[3] = wall_clock64();
         }
     } else
-    if (p.out32 == nullptr && p.residual == nullptr) {
-        // 16-bit staging: 2 passes of 4 row-fragments; LDS row = BN * 2 + 16 bytes
-        constexpr int ROWB = BN * 2 + 16, CPR = BN * 2 / 16, MTP = 4, ROWS = 2 * MTP * 16;
+    if (PERSIST_16 || (p.out32 == nullptr && p.residual == nullptr)) {
+        // 16-bit staging: 2 passes of 4 row-fragments (PERSIST: 4 passes of 2, above the two slots the next tile's first
+        // K-steps are landing in); LDS row = BN * 2 + 16 bytes
+        constexpr int ROWB = BN * 2 + 16, CPR = BN * 2 / 16, MTP = PERSIST ? 2 : 4, ROWS = 2 * MTP * 16;
         static_assert(EPI_BASE + ROWS * ROWB <= LDS_TOTAL && (ROWS * CPR) % 512 == 0, "epilogue staging");
-        auto epi_sync = [&]() { __syncthreads(); };
+        auto epi_sync = [&]() {                              // PERSIST: a raw barrier (a __syncthreads would drain the prefetch)
+            if constexpr (PERSIST) { __builtin_amdgcn_s_waitcnt(0xc07f); barrier(); } else __syncthreads();
+        };
 #pragma unroll
         for (int q = 0; q < C::MT / MTP; ++q) {
 #pragma unroll
@@ -397,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             if constexpr (DBG) { if (q < 2) we[2 + 2 * q] = wall_clock64(); }
             if (q + 1 < C::MT / MTP) epi_sync();
         }
-    } else if (p.residual != nullptr) {
+    } else if (!PERSIST_16 && p.residual != nullptr) {
         // fp32 + residual: 8 passes of one row-fragment (32 rows).  Pass q: request the residual rows of pass q + 1,
         // stage this pass's accumulators, wait for this wave's residual pieces of pass q (everything but the DMA
         // just issued is complete: the C stores of pass q - 1 are older and have had a pass to be acknowledged),
@@ -413,6 +473,11 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             if (q + 1 < C::MT) wait_vmcnt<RP_PW>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): staging writes done
             barrier();
+            if constexpr (PERSIST) {
+                // the next tile's step 0 into slot 0 (below this epilogue's LDS), issued after pass 0's wait so that no
+                // epilogue wait has to sit out its round trip: by pass 1's wait it has had a pass to land
+                if (q == 0 && has_next) { prefetch_next(1); next_issued = 1; }
+            }
             const char* land = smem + ((q & 1) ? RES_L1 : RES_L0);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -433,11 +498,13 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
                 barrier();
             }
         }
-    } else {
+    } else if constexpr (!PERSIST_16) {
         // fp32 staging: 4 passes of 2 row-fragments; LDS row = BN * 4 + 16 bytes
         constexpr int ROWB = BN * 4 + 16, CPR = BN * 4 / 16, MTP = 2, ROWS = 2 * MTP * 16;
         static_assert(EPI_BASE + ROWS * ROWB <= LDS_TOTAL && (ROWS * CPR) % 512 == 0, "epilogue staging");
-        auto epi_sync = [&]() { __syncthreads(); };
+        auto epi_sync = [&]() {
+            if constexpr (PERSIST) { __builtin_amdgcn_s_waitcnt(0xc07f); barrier(); } else __syncthreads();
+        };
 #pragma unroll
         for (int q = 0; q < C::MT / MTP; ++q) {
 #pragma unroll
@@ -471,6 +538,15 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         else if (act == ACT_RELU) epilogue(std::integral_constant<int, ACT_RELU>{});
         else epilogue(std::integral_constant<int, ACT_NONE>{});
     }
+    if constexpr (PERSIST) {
+        if (!has_next) break;
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // this wave's reads of the epilogue staging / landing buffers are back
+        barrier();                                          // before anyone's K-loop DMA (slot 2, landing buffer 0) reuses that LDS
+        tile = next_tile; m0 = nm0; n0 = nn0; pre_issued = next_issued;
+    } else {
+        break;
+    }
+    }                                                       // tiles
     if constexpr (DBG) {
         if (wave == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // C stores of this wave acknowledged

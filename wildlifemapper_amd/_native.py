@@ -19,12 +19,15 @@ GEMM_VARIANTS = ("v1_128", "v2_160", "v2_128", "v3_lockstep", "v3_conv3x3", "v5_
                  "v5_320_lnf", "v5_256_lnf", "fp8_320", "fp8_256")
 FLAG_CONF, FLAG_SCORE, FLAG_NMS, FLAG_MERGED = 1, 2, 4, 8
 CFG_FUSE_LN = 1
+ABI_VERSION = 2            # include/wm_hip.h WM_ABI_VERSION this binding was written for
+FP8_QKV, FP8_PROJ, FP8_MLP, FP8_ALL = 1, 2, 4, 7
+SAT_NAMES = ("layernorm_out", "qkv", "attention_out", "mlp_hidden", "last_block_16")
 
 
 class WmConfig(C.Structure):
     _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32),
                 ("num_global", C.c_int32), ("global_attn_indexes", C.c_int32 * 8),
-                ("max_batch", C.c_int32), ("precision", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("max_batch", C.c_int32), ("precision", C.c_int32), ("flags", C.c_int32), ("fp8_gemms", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class WmBoxRecord(C.Structure):
@@ -63,6 +66,8 @@ SYMBOLS = {
     "wm_profile_read": (_I, [_P, C.POINTER(WmKclassStat)]),
     "wm_debug_gemm_variant_counts": (_I, [C.POINTER(_L), _I]),
     "wm_debug_reset_gemm_variant_counts": (_I, []),
+    "wm_debug_saturation_enable": (_I, [_P, _I]),
+    "wm_debug_saturation_read": (_I, [_P, C.POINTER(_L), _I, _I, _P]),
     "wm_op_cvt_f32_to_16": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_cvt_16_to_f32": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_gemm16": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -93,8 +98,10 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)       # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if l.wm_abi_version() != 1:
-            raise RuntimeError("libwm_hip.so ABI version mismatch")
+        got = l.wm_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {got}, this binding was written for {ABI_VERSION}: "
+                               "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
         _lib = l
     return _lib
 

@@ -118,7 +118,7 @@ class CocoBboxEval:
         for a in dataset.get("annotations", []):
             x, y, w, h = [float(v) for v in a["bbox"]]
             rec = {"box": (x, y, x + w, y + h), "area": float(a.get("area", w * h)), "crowd": int(a.get("iscrowd", 0)),
-                   "ignore": int(a.get("ignore", 0)) or int(a.get("iscrowd", 0))}
+                   "ignore": int(a.get("iscrowd", 0))}       # the published COCOeval._prepare overwrites gt['ignore'] with iscrowd
             self.gts.setdefault((int(a["image_id"]), int(a["category_id"])), []).append(rec)
         if not self.cat_ids:
             self.cat_ids = sorted({k[1] for k in self.gts})
@@ -263,8 +263,8 @@ def _as_coco_dataset(base_ds) -> Mapping:
 
 class CocoEvaluator:
     """Same surface as the reference's CocoEvaluator (inference.py:92-171): update / synchronize_between_processes /
-    accumulate / summarize, `.coco_eval['bbox'].stats`.  Rank merge: fixed-size detection records through ONE padded
-    all-gather (wildlifemapper_amd.dist.gather_detections), not the reference's pickle gather (utils/misc.py:180-220)."""
+    accumulate / summarize, `.coco_eval['bbox'].stats`.  Rank merge: fixed-size detection records through one padded
+    all-gather behind a 2-word status all-reduce (wildlifemapper_amd.dist.gather_detections), not the reference's pickle gather (utils/misc.py:180-220)."""
 
     def __init__(self, coco_gt, iou_types=("bbox",)) -> None:
         assert isinstance(iou_types, (list, tuple))

@@ -199,6 +199,29 @@ __global__ __launch_bounds__(256) void cvt_f32_to_16_kernel(const float* __restr
     }
 }
 
+// Opt-in saturation census (wm_debug_saturation_*): elements of a 16-bit buffer whose magnitude bits are >= `thr` (fp16:
+// 0x7bff = 65504, the value T::from_f32 clamps to, and inf / NaN above it; bf16: 0x7f7f and above), or of an e4m3 byte
+// buffer with magnitude >= 0x7e (448).  One atomic per workgroup.  16 bytes per thread and iteration.
+template <int BYTES_PER_ELEM>
+__global__ __launch_bounds__(256) void saturation_count_kernel(const uint4* __restrict__ in, int64_t n16, unsigned thr, unsigned long long* __restrict__ counter) {
+    unsigned c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+        const uint4 v = in[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (BYTES_PER_ELEM == 2) {
+                c += ((w[j] & 0x7fffu) >= thr) + (((w[j] >> 16) & 0x7fffu) >= thr);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) c += (((w[j] >> (8 * b)) & 0x7fu) >= thr);
+            }
+        }
+    }
+    c = (unsigned)wave_sum((float)c);                  // <= 64 * 16 * iterations: exact in fp32 for any realistic grid
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(counter, (unsigned long long)c);
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void cvt_16_to_f32_kernel(const u16* __restrict__ in, float* __restrict__ out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {

@@ -18,8 +18,6 @@
 
 #include "../../include/wm_hip.h"
 #include "attn16.h"
-#include "attn_win2.h"
-#include "attn_glob2.h"
 #include "dec_kernels.h"
 #include "fft_kernels.h"
 #include "gemm16.h"
@@ -30,6 +28,13 @@
 #include "gemm8.h"
 #include "misc_kernels.h"
 #include "wm_common.h"
+
+// Dev instrumentation (in-kernel timelines of the GEMMs: tools/gemm_bench.py with WM_GEMM_DBG / WM_GEMM8_DBG /
+// WM_LNF_TIMELINE) is compiled only with -DWM_DEV_TIMELINE=1 (tools/build_dev.sh); the product library carries neither
+// the instrumented kernel instances nor their environment switches.
+#ifndef WM_DEV_TIMELINE
+#define WM_DEV_TIMELINE 0
+#endif
 
 using namespace wm;
 
@@ -210,6 +215,7 @@ struct LnFuseState {
 struct wm_handle {
     wm_config cfg{};
     LnFuseState lnf;
+    int fp8_gemms = WM_FP8_ALL;             // fp8 mode: which of a block's GEMMs run e4m3 (wm_config.fp8_gemms, 0 = all)
     int fp8_bf16_tail = 0, fp8_bf16_head = 0;  // fp8 mode: the first / last blocks that stay bf16 (env WM_FP8_BF16_HEAD / _TAIL, default 0)
     int fp16_tail = 0;      // bf16 mode: the last fp16_tail transformer blocks use fp16 operands (parity margin dial; default 0)
     int device = 0;
@@ -221,10 +227,11 @@ struct wm_handle {
     std::map<std::string, uint16_t*> w16;
     std::map<std::string, uint8_t*> w8;     // WM_PREC_FP8: e4m3 weights of the blocks' GEMMs; their per-channel scales live in w32[name + ".wscale"]
     uint8_t* ao8 = nullptr;                 // attention output as e4m3 (A operand of proj)
-    uint16_t* win_cpage = nullptr;          // constant page of the LDS-DMA window attention (attn_win2.h): [3D + 80] 16-bit
     std::map<std::string, float*> w32;
     std::vector<void*> allocs;
     Profiler prof;
+    bool sat_on = false;                    // wm_debug_saturation_enable
+    unsigned long long* sat_counts = nullptr;   // [WM_SAT_COUNT] device counters
     int tap_which = -2;
     float* tap_buf = nullptr;
 
@@ -318,27 +325,6 @@ int launch_gemm16v2_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     return 0;
 }
 
-template <class T16, int BN, int WN>
-int launch_gemm16v3_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
-    using G = G3<BN, WN>;
-    WM_TRY(set_max_lds((const void*)gemm16v3_kernel<T16, BN, WN>, G::LDS));
-    count_variant(WM_GEMM_V3_LOCKSTEP);
-    const int grid = (a.M / 256) * (a.N / BN);
-    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
-               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
-    hipLaunchKernelGGL((gemm16v3_kernel<T16, BN, WN>), dim3(grid), dim3(G::THREADS), G::LDS, s, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// Row tiles per group of the staggered kernel's tile order (Gemm16Args::group_m).  WM_GEMM_GROUP_M=n overrides (A/B runs).
-static int gemm_group_m(int tilesM, int tilesN) {
-    const char* e = getenv("WM_GEMM_GROUP_M");
-    if (e && atoi(e) > 0) return atoi(e);
-    (void)tilesM; (void)tilesN;
-    return G16_GROUP_M;
-}
-
 template <class T16, int BN, int NSLOT = 3>
 int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
     using G = G3<BN, 4>;
@@ -348,9 +334,9 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
     count_variant(BN == 320 ? (a_in.residual ? WM_GEMM_V5_320_RES : WM_GEMM_V5_320) : (a_in.residual ? WM_GEMM_V5_256_RES : WM_GEMM_V5_256));
     const int grid = (a_in.M / 256) * (a_in.N / BN);
     Gemm16Args a = a_in;
-    a.group_m = gemm_group_m(a.M / 256, a.N / BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
+#if WM_DEV_TIMELINE
     if constexpr (BN == 320 && NSLOT == 3) {
         static const bool dbg = getenv("WM_GEMM_DBG") != nullptr;          // dev: in-kernel interval timing of workgroup 0
         static int dbg_count = 0;          // instrument the 1st and, after a run of back-to-back launches, the 31st
@@ -409,20 +395,7 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
             return 0;
         }
     }
-    // Persistent instance (one workgroup per CU walks its tiles and requests the next tile's first K-steps during the epilogue),
-    // 16-bit-output GEMMs only.  OFF by default: bit-identical, but measured 7-15 % slower at BN = 320 and +-2 % at BN = 256
-    // (tools/ab_persist.py); WM_GEMM_PERSIST=1 enables it.
-    if constexpr (NSLOT == 3) {
-        const char* pe = getenv("WM_GEMM_PERSIST");
-        const int cus = num_cus();
-        if (pe && atoi(pe) != 0 && grid >= 2 * cus && cus % 8 == 0 && !a.residual && !a.out32 && a.out16) {
-            constexpr int LDSP = 160 * 1024;
-            WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, NSLOT, false, false, true>, LDSP));
-            hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, NSLOT, false, false, true>), dim3(cus), dim3(512), LDSP, s, a);
-            HIP_TRY(hipGetLastError());
-            return 0;
-        }
-    }
+#endif
     hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, NSLOT>), dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -480,6 +453,7 @@ int launch_gemm16v5_ln_t(wm_handle* h, hipStream_t s, Gemm16Args a) {
     const int grid = mtiles * tn;
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + 10.0 * a.M * a.N);
+#if WM_DEV_TIMELINE
     static const bool timeline = getenv("WM_LNF_TIMELINE") != nullptr;       // dev: per-workgroup stamps of the fused epilogue
     static int tl_count = 0;
     if (timeline && ++tl_count == 12) {
@@ -504,6 +478,7 @@ int launch_gemm16v5_ln_t(wm_handle* h, hipStream_t s, Gemm16Args a) {
                 "pass B avg %.2f us; last workgroup done %.2f us after the first pass-A end\n", a.M, a.N, a.K, m1 - mn1, a1 / grid, a2 / grid, m3, a3 / grid, mx_end);
         return 0;
     }
+#endif
     hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, true>), dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -513,11 +488,10 @@ int launch_gemm16v5_ln_t(wm_handle* h, hipStream_t s, Gemm16Args a) {
 // nothing) when the shape cannot be fused; the caller then runs the GEMM and the LayerNorm kernel separately.
 int launch_gemm16_ln(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias, const float* res,
                      float* out32, void* out16, const float* gamma, const float* beta, float eps, int M, int N, int K) {
-    static const bool mode0 = !getenv("WM_GEMM_MODE") || atoi(getenv("WM_GEMM_MODE")) == 0;
     const bool off = h && !(h->cfg.flags & WM_CFG_FUSE_LN);          // engine: opt-in; the single-op entry always fuses
     const int bn = ln_fuse_bn(M, N, K);
-    if (off || !mode0 || !bn || !res || !out32 || !out16 || !gamma || !beta) return 1;
-    static const int dbg_bits = getenv("WM_LNF_DBG") ? atoi(getenv("WM_LNF_DBG")) : 0;     // timing experiments: 256 no LN stores, 1024 no wait
+    if (off || !bn || !res || !out32 || !out16 || !gamma || !beta) return 1;
+    constexpr int dbg_bits = 0;
     Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, 0, ACT_NONE | dbg_bits, 0, nullptr, gamma, beta, eps, nullptr, nullptr, 0};
     if (bn == 320) return prec == WM_PREC_FP16 ? launch_gemm16v5_ln_t<FP16, 320>(h, s, a) : launch_gemm16v5_ln_t<BF16, 320>(h, s, a);
     return prec == WM_PREC_FP16 ? launch_gemm16v5_ln_t<FP16, 256>(h, s, a) : launch_gemm16v5_ln_t<BF16, 256>(h, s, a);
@@ -540,14 +514,6 @@ int ln_fuse_check(wm_handle* h, hipStream_t s) {
 // fraction of the last round of workgroup slots that is filled
 static double round_eff(long tiles, long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); }
 
-// WM_GEMM_MODE (A/B runs): 0 = auto: 256x320 / 256x256 8-wave tiles with staggered wave groups (gemm16_v5.h), else 256x160/128
-//                          4 = as 0 but lockstep waves (gemm16_v3.h)
-//                          1 = 128x128 kernel only   2 = gemm16_v2.h only   3 = 4-wave 256x160/128 (two workgroups per CU)
-static int gemm_mode() {
-    static const int m = getenv("WM_GEMM_MODE") ? atoi(getenv("WM_GEMM_MODE")) : 0;
-    return m;
-}
-
 #define WM_BY_PREC(call_bf16, call_fp16) (prec == WM_PREC_FP16 ? (call_fp16) : (call_bf16))
 
 int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias,
@@ -556,9 +522,8 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
         return fail("gemm16: shape M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, G16_BM, G16_BN, G16_BK);
     if (!out32 && !out16) return fail("gemm16: no output");
     Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act, 0, nullptr};
-    const int mode = gemm_mode();
-    if (M % 256 == 0 && mode != 1) {
-        if (mode == 0 && K / 32 >= 2) {      // staggered wave groups (gemm16_v5.h)
+    if (M % 256 == 0) {
+        if (K / 32 >= 2) {      // staggered wave groups (gemm16_v5.h)
             // Few tiles (one or two image tiles per call): the half-width 256 x 160 / 128 kernel fills more CUs.  Cost
             // model from tools/gemm_bench.py --batch 1: rounds of 256 workgroups x (1.0 | 0.6) per tile.
             auto prefer_half = [&](int bn) {
@@ -567,30 +532,22 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
             };
             if (N % 320 == 0 && !prefer_half(320)) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320>(h, s, a)), (launch_gemm16v5_t<FP16, 320>(h, s, a)));
             if (N % 320 != 0 && N % 256 == 0 && !prefer_half(256)) return WM_BY_PREC((launch_gemm16v5_t<BF16, 256>(h, s, a)), (launch_gemm16v5_t<FP16, 256>(h, s, a)));
-            if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v2_t<BF16, 160>(h, s, a)), (launch_gemm16v2_t<FP16, 160>(h, s, a)));
-            if (N % 256 == 0) return WM_BY_PREC((launch_gemm16v2_t<BF16, 128>(h, s, a)), (launch_gemm16v2_t<FP16, 128>(h, s, a)));
         }
-        if (mode == 0 || mode == 4) {
-            if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v3_t<BF16, 320, 4>(h, s, a)), (launch_gemm16v3_t<FP16, 320, 4>(h, s, a)));
-            if (N % 256 == 0) return WM_BY_PREC((launch_gemm16v3_t<BF16, 256, 4>(h, s, a)), (launch_gemm16v3_t<FP16, 256, 4>(h, s, a)));
-        }
-        const long slots = mode == 3 ? 512 : 256;
+        // half-width tiles: 256 x 160 where N allows and it fills the last round at least as well as 256 x 128
         const bool can160 = N % 160 == 0;
-        const bool use160 = can160 && round_eff((long)(M / 256) * (N / 160), slots) >= round_eff((long)(M / 256) * (N / 128), slots) - 1e-9;
-        if (mode == 3) {
-            if (use160) return WM_BY_PREC((launch_gemm16v3_t<BF16, 160, 2>(h, s, a)), (launch_gemm16v3_t<FP16, 160, 2>(h, s, a)));
-            return WM_BY_PREC((launch_gemm16v3_t<BF16, 128, 2>(h, s, a)), (launch_gemm16v3_t<FP16, 128, 2>(h, s, a)));
-        }
+        const bool use160 = can160 && (N % 320 == 0 || round_eff((long)(M / 256) * (N / 160), 256) >= round_eff((long)(M / 256) * (N / 128), 256) - 1e-9);
         if (use160) return WM_BY_PREC((launch_gemm16v2_t<BF16, 160>(h, s, a)), (launch_gemm16v2_t<FP16, 160>(h, s, a)));
         return WM_BY_PREC((launch_gemm16v2_t<BF16, 128>(h, s, a)), (launch_gemm16v2_t<FP16, 128>(h, s, a)));
     }
     return WM_BY_PREC((launch_gemm16_t<BF16>(h, s, a)), (launch_gemm16_t<FP16>(h, s, a)));
 }
 
-// fp8 GEMM (gemm8.h).  prec16 = type of a 16-bit output.  WM_GEMM8_BK=128|64 picks the K-step variant (A/B runs).
+// fp8 GEMM (gemm8.h).  prec16 = type of a 16-bit output.  K-step 128 (the 64-byte / 4-slot variant measured equal or
+// 1-3 % slower: tools/experiments/gemm8_bk64.h, profiles/r2_dev/gemm8_bench_b16_bk64.txt).
 template <class T16, int BKB>
 int launch_gemm8_t(wm_handle* h, hipStream_t s, Gemm8Args a, int grid, double flops, double bytes) {
     using G = G8<BKB>;
+#if WM_DEV_TIMELINE
     static const bool dbg = getenv("WM_GEMM8_DBG") != nullptr;          // dev: per-workgroup wall-clock stamps of the 5th launch
     static int dbg_count = 0;
     if (dbg && ++dbg_count == 5) {
@@ -626,6 +583,7 @@ int launch_gemm8_t(wm_handle* h, hipStream_t s, Gemm8Args a, int grid, double fl
                 loop / grid * 10.0 / (a.K / 128.0), epi / grid * 0.01, grid);
         return 0;
     }
+#endif
     WM_TRY(set_max_lds((const void*)gemm8_kernel<T16, BKB>, G::LDS));
     Bracket br(h, s, WM_KCLASS_GEMM16, flops, bytes);
     hipLaunchKernelGGL((gemm8_kernel<T16, BKB>), dim3(grid), dim3(512), G::LDS, s, a);
@@ -635,7 +593,6 @@ int launch_gemm8_t(wm_handle* h, hipStream_t s, Gemm8Args a, int grid, double fl
 
 int launch_gemm8(wm_handle* h, hipStream_t s, int prec16, const void* A, const void* W, const float* wscale, const float* bias,
                  const float* res, float* out32, void* out16, void* out8, int M, int N, int K, int act) {
-    const int bk = getenv("WM_GEMM8_BK") ? atoi(getenv("WM_GEMM8_BK")) : 128;     // 128 measured >= 64 on every block shape
     if (M <= 0 || N <= 0 || K <= 0 || M % G8_BM || N % G8_BN || K % 128 || K < 256)
         return fail("gemm8: shape M=%d N=%d K=%d must be multiples of %d/%d/128 with K >= 256", M, N, K, G8_BM, G8_BN);
     if (!A || !W || !wscale) return fail("gemm8: null operand");
@@ -646,12 +603,8 @@ int launch_gemm8(wm_handle* h, hipStream_t s, int prec16, const void* A, const v
     count_variant(WM_GEMM_FP8_256);
     const double flops = 2.0 * M * (double)N * K;
     const double bytes = (double)M * K + (double)N * K + (res ? 8.0 : 0.0) * M * N + (out16 ? 2.0 : 0.0) * M * N + (out8 ? 1.0 : 0.0) * M * N;
-    if (bk == 128) {
-        if (prec16 == WM_PREC_FP16) return launch_gemm8_t<FP16, 128>(h, s, a, grid, flops, bytes);
-        return launch_gemm8_t<BF16, 128>(h, s, a, grid, flops, bytes);
-    }
-    if (prec16 == WM_PREC_FP16) return launch_gemm8_t<FP16, 64>(h, s, a, grid, flops, bytes);
-    return launch_gemm8_t<BF16, 64>(h, s, a, grid, flops, bytes);
+    if (prec16 == WM_PREC_FP16) return launch_gemm8_t<FP16, 128>(h, s, a, grid, flops, bytes);
+    return launch_gemm8_t<BF16, 128>(h, s, a, grid, flops, bytes);
 }
 
 // 3x3 / pad 1 convolution over an NHWC [B,64,64,C] 16-bit activation as an implicit GEMM (no im2col buffer):
@@ -685,6 +638,8 @@ int launch_gemm32(wm_handle* h, hipStream_t s, const float* A, const float* W, c
 int launch_layernorm(wm_handle* h, hipStream_t s, int prec, const float* x, const float* g, const float* b, float eps,
                      float* out32, void* out16, int64_t rows, int C, int nchw_hw = 0) {
     if (C % 256 || C > 1280) return fail("layernorm: C=%d unsupported (multiple of 256, <= 1280)", C);
+    if (prec != WM_PREC_BF16 && prec != WM_PREC_FP16)
+        return fail("layernorm: precision %d has no fp32-output / general form (e4m3 output exists only for the blocks' 16-bit-only form)", prec);
     const dim3 grid((unsigned)((rows + 3) / 4));
     Bracket br(h, s, WM_KCLASS_LAYERNORM, 0.0, (double)rows * C * (4.0 + (out32 ? 4.0 : 0.0) + (out16 ? 2.0 : 0.0)));
 #define LN_CASE(NV)                                                                                                   \
@@ -728,18 +683,6 @@ int launch_layernorm_block(wm_handle* h, hipStream_t s, int prec, const float* x
 
 template <class T16, int HD, bool REL>
 int launch_attn_global_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int batch, int kclass) {
-    // WM_ATTN_GLOBAL=2: two query blocks per wave, one wave per SIMD (attn_glob2.h): correct (same tests), 12-18 % slower than
-    // the default kernel on the encoder shape and 35-55 % slower at head_dim 128; kept as the measured experiment
-    const char* e = getenv("WM_ATTN_GLOBAL");
-    if (e && atoi(e) == 2 && a.nq % 256 == 0) {
-        using L2 = Global2Lds<HD, REL>;
-        WM_TRY(set_max_lds((const void*)attn_global2_kernel<T16, HD, REL>, L2::TOTAL));
-        Bracket br(h, s, kclass, 4.0 * batch * a.heads * (double)a.nq * a.nk * HD, 0.0);
-        const int nqb = a.nq / 256;
-        hipLaunchKernelGGL((attn_global2_kernel<T16, HD, REL>), dim3(nqb * a.heads * batch), dim3(256), L2::TOTAL, s, a, nqb);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
     using L = GlobalLds<HD, REL>;
     WM_TRY(set_max_lds((const void*)attn_global_kernel<T16, HD, REL>, L::TOTAL));
     Bracket br(h, s, kclass, 4.0 * batch * a.heads * (double)a.nq * a.nk * HD, 0.0);
@@ -765,40 +708,10 @@ int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
     const int num_cu = num_cus();
     const int nitems = 25 * a.heads * batch;
     const int grid = nitems < num_cu ? nitems : num_cu;
-    // default: first-generation kernel (register staging, online softmax).  WM_ATTN_WIN=2: the LDS-DMA / exact-softmax kernel
-    // (attn_win2.h): correct (same tests) but 27 % slower at B = 16 (334 vs 263 us), kept as the measured experiment
-    const char* e = getenv("WM_ATTN_WIN");
-    if (!(e && atoi(e) == 2)) {
-        using L = WindowLds<HD>;
-        WM_TRY(set_max_lds((const void*)attn_window_kernel<T16, HD>, L::TOTAL));
-        Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);   // useful work only
-        hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(grid), dim3(448), L::TOTAL, s, a, nitems);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    using L = Window2Lds<HD>;
-    const int D = a.heads * HD;
-    // constant page of the DMA sources (16-bit qkv bias, zero chunk, ones chunk): the handle's, or a per-device one for the
-    // handle-less single-op entry (tests; not for concurrent streams)
-    uint16_t* cpage = h ? h->win_cpage : nullptr;
-    if (!cpage) {
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        static std::map<int, std::pair<uint16_t*, int>> pages;
-        std::lock_guard<std::mutex> lk(g_dev_mu);
-        auto& pg = pages[dev];
-        if (pg.second < 3 * D + 128) {
-            if (pg.first) HIP_TRY(hipFree(pg.first));
-            pg.first = nullptr; pg.second = 0;
-            HIP_TRY(hipMalloc((void**)&pg.first, (size_t)(3 * D + 128) * 2));
-            pg.second = 3 * D + 128;
-        }
-        cpage = pg.first;
-    }
-    WM_TRY(set_max_lds((const void*)attn_window2_kernel<T16, HD>, L::TOTAL));
-    Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);       // useful work only
-    hipLaunchKernelGGL((attn_win2_cpage_kernel<T16>), dim3(4), dim3(256), 0, s, a.qkv_bias, cpage, 3 * D);
-    hipLaunchKernelGGL((attn_window2_kernel<T16, HD>), dim3(grid), dim3(448), L::TOTAL, s, a, nitems, (const u16*)cpage);
+    using L = WindowLds<HD>;
+    WM_TRY(set_max_lds((const void*)attn_window_kernel<T16, HD>, L::TOTAL));
+    Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);   // useful work only
+    hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(grid), dim3(448), L::TOTAL, s, a, nitems);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -971,9 +884,11 @@ static bool is_fp8_block_gemm(const wm_handle* h, const std::string& name) {
     const std::string pre = "image_encoder.blocks.";
     if (h->prec != WM_PREC_FP8 || name.rfind(pre, 0) != 0) return false;
     if (block_prec(h, atoi(name.c_str() + pre.size())) != WM_PREC_FP8) return false;
-    for (const char* suf : {"attn.qkv.weight", "attn.proj.weight", "mlp.lin1.weight", "mlp.lin2.weight"}) {
-        const size_t n = strlen(suf);
-        if (name.size() >= n && name.compare(name.size() - n, n, suf) == 0) return true;
+    const std::pair<const char*, int> sufs[] = {{"attn.qkv.weight", WM_FP8_QKV}, {"attn.proj.weight", WM_FP8_PROJ},
+                                                {"mlp.lin1.weight", WM_FP8_MLP}, {"mlp.lin2.weight", WM_FP8_MLP}};
+    for (const auto& sf : sufs) {
+        const size_t n = strlen(sf.first);
+        if (name.size() >= n && name.compare(name.size() - n, n, sf.first) == 0) return (h->fp8_gemms & sf.second) != 0;
     }
     return false;
 }
@@ -1058,6 +973,8 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     h->fp16_tail = getenv("WM_FP16_TAIL") ? atoi(getenv("WM_FP16_TAIL")) : 0;
     h->fp8_bf16_tail = getenv("WM_FP8_BF16_TAIL") ? atoi(getenv("WM_FP8_BF16_TAIL")) : 0;
     h->fp8_bf16_head = getenv("WM_FP8_BF16_HEAD") ? atoi(getenv("WM_FP8_BF16_HEAD")) : 0;
+    h->fp8_gemms = cfg->fp8_gemms ? (cfg->fp8_gemms & WM_FP8_ALL) : (getenv("WM_FP8_GEMMS") ? (atoi(getenv("WM_FP8_GEMMS")) & WM_FP8_ALL) : WM_FP8_ALL);
+    if (cfg->precision == WM_PREC_FP8 && h->fp8_gemms == 0) { delete h; return fail("wm_create: fp8_gemms selects no GEMM"); }
     h->D = cfg->embed_dim; h->depth = cfg->depth; h->heads = cfg->num_heads; h->hd = hd;
     h->prec = cfg->precision; h->maxB = cfg->max_batch;
     for (int i = 0; i < cfg->num_global; ++i) {
@@ -1086,8 +1003,8 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     A(hfc, B * 1024 * 1024 * 4); A(tsz_default, B * 2 * 4);
     A(fftR, B * FFT_N * FFT_L * sizeof(float2)); A(fft_tw, FFT_N * sizeof(float2));
     A(kpe, (size_t)T * OUTC * 4);
-    A(win_cpage, (3 * D + 128) * 2);
     A(records, B * NQ * sizeof(wm_box_record));
+    A(sat_counts, WM_SAT_COUNT * sizeof(unsigned long long));
 #undef A
     if (r) { wm_destroy(h); return r; }
     // FFT twiddles exp(-2 pi i k / 1024), computed in double
@@ -1100,6 +1017,7 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
         hipError_t e = hipMemcpy(h->fft_tw, tw.data(), FFT_N * sizeof(float2), hipMemcpyHostToDevice);
         std::vector<float> ts(B * 2, 1024.f);
         if (e == hipSuccess) e = hipMemcpy(h->tsz_default, ts.data(), B * 2 * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(h->sat_counts, 0, WM_SAT_COUNT * sizeof(unsigned long long));
         if (e != hipSuccess) { wm_destroy(h); return fail("wm_create: twiddle upload failed: %s", hipGetErrorString(e)); }
     }
     *out = h;
@@ -1260,6 +1178,20 @@ int fft_impl(wm_handle* h, const float* x, float* out, int B, hipStream_t s) {
     return 0;
 }
 
+// opt-in census of clamped values in a 16-bit / e4m3 activation buffer (wm_debug_saturation_enable); prec = element type
+int sat_check(wm_handle* h, hipStream_t s, int which, const void* buf, int64_t n_elems, int prec) {
+    if (!h->sat_on) return 0;
+    const int64_t bytes = n_elems * (prec == WM_PREC_FP8 ? 1 : 2);
+    if (bytes % 16) return fail("saturation census: buffer of %lld bytes", (long long)bytes);
+    const unsigned thr = prec == WM_PREC_FP8 ? 0x7eu : (prec == WM_PREC_FP16 ? 0x7bffu : 0x7f7fu);
+    if (prec == WM_PREC_FP8)
+        hipLaunchKernelGGL(saturation_count_kernel<1>, dim3(grid_for(bytes / 16)), dim3(256), 0, s, (const uint4*)buf, bytes / 16, thr, h->sat_counts + which);
+    else
+        hipLaunchKernelGGL(saturation_count_kernel<2>, dim3(grid_for(bytes / 16)), dim3(256), 0, s, (const uint4*)buf, bytes / 16, thr, h->sat_counts + which);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw, int B, hipStream_t s) {
     const int D = h->D, P = h->prec, M = B * T;
     const int PS = WM_PREC_FP16;      // stem, HFC adaptor and neck: fp16 operands in every mode (see is_stem_or_neck)
@@ -1302,63 +1234,78 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     // ---- transformer blocks (image_encoder.py:188-204) ----
     // x = x + proj(attn(norm1 x)); x = x + lin2(gelu(lin1(norm2 x))).  The two residual GEMMs also produce the following
     // LayerNorm's output where the shape allows (launch_gemm16_ln returns 1 otherwise and the separate kernels run).
+    // Per GEMM the operand type is the block's (block_prec) or, in fp8 mode, e4m3 for the GEMMs the handle's fp8 mask names
+    // (WM_FP8_QKV | WM_FP8_PROJ | WM_FP8_MLP; lin1 and lin2 go together because lin1's epilogue writes lin2's operand) and
+    // bf16 for the rest and for attention.  Each producer writes its consumer's operand type directly (LayerNorm / attention /
+    // GELU epilogue -> e4m3 bytes or 16-bit), so no conversion pass exists in any mix.
     bool xn_ready = false;                                  // xn16 already holds norm1 of the current residual stream
     for (int i = 0; i < h->depth; ++i) {
         const std::string b = e + "blocks." + std::to_string(i) + ".";
-        const int P = block_prec(h, i);
-        if (P == WM_PREC_FP8) {
-            // BASELINE.json configs[4]: the four projections on the fp8 MFMA (gemm8.h), e4m3 activations from the LayerNorm /
-            // convert / GELU epilogues, attention on the bf16 kernels
-            auto W8 = [&](const std::string& n) { return h->w8.at(n); };
-            WM_TRY(launch_layernorm_block(h, s, P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D));
-            WM_TRY(launch_gemm8(h, s, WM_PREC_BF16, h->xn16, W8(b + "attn.qkv.weight"), W32(h, b + "attn.qkv.weight.wscale"), W32(h, b + "attn.qkv.bias"),
+        const int PB = block_prec(h, i);
+        const bool f8 = PB == WM_PREC_FP8;
+        const int P = f8 ? WM_PREC_BF16 : PB;               // 16-bit type of this block (attention, non-fp8 GEMMs)
+        const bool q8 = f8 && (h->fp8_gemms & WM_FP8_QKV), p8 = f8 && (h->fp8_gemms & WM_FP8_PROJ), m8 = f8 && (h->fp8_gemms & WM_FP8_MLP);
+        auto W8 = [&](const std::string& n) { return h->w8.at(n); };
+        if (!xn_ready)
+            WM_TRY(launch_layernorm_block(h, s, q8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D));
+        WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, q8 ? WM_PREC_FP8 : P));
+        if (q8)
+            WM_TRY(launch_gemm8(h, s, P, h->xn16, W8(b + "attn.qkv.weight"), W32(h, b + "attn.qkv.weight.wscale"), W32(h, b + "attn.qkv.bias"),
                                 nullptr, nullptr, h->qkv16, nullptr, M, 3 * D, D, ACT_NONE));
-            // the attention kernels write their output directly as e4m3 (the A operand of proj)
-            WM_TRY(launch_encoder_attention(h, s, WM_PREC_BF16, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
-                                            W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14, h->ao8));
-            WM_TRY(launch_gemm8(h, s, WM_PREC_BF16, h->ao8, W8(b + "attn.proj.weight"), W32(h, b + "attn.proj.weight.wscale"), W32(h, b + "attn.proj.bias"),
-                                h->resid, h->resid, nullptr, nullptr, M, D, D, ACT_NONE));
-            WM_TRY(launch_layernorm_block(h, s, P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D));
-            WM_TRY(launch_gemm8(h, s, WM_PREC_BF16, h->xn16, W8(b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.weight.wscale"), W32(h, b + "mlp.lin1.bias"),
-                                nullptr, nullptr, nullptr, h->hid16, M, 4 * D, D, ACT_GELU));
-            WM_TRY(launch_gemm8(h, s, WM_PREC_BF16, h->hid16, W8(b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.weight.wscale"), W32(h, b + "mlp.lin2.bias"),
-                                h->resid, h->resid, nullptr, nullptr, M, D, 4 * D, ACT_NONE));
-            xn_ready = false;
-            WM_TRY(do_tap(h, s, i, B));
-            continue;
-        }
-        if (!xn_ready)
-            WM_TRY(launch_layernorm_block(h, s, P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D));
-        WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "attn.qkv.weight"), W32(h, b + "attn.qkv.bias"), nullptr, 0, nullptr,
-                             h->qkv16, M, 3 * D, D, ACT_NONE));
+        else
+            WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "attn.qkv.weight"), W32(h, b + "attn.qkv.bias"), nullptr, 0, nullptr,
+                                 h->qkv16, M, 3 * D, D, ACT_NONE));
+        WM_TRY(sat_check(h, s, WM_SAT_QKV, h->qkv16, (int64_t)M * 3 * D, P));
+        // the attention kernels write their output as e4m3 when proj consumes e4m3
         WM_TRY(launch_encoder_attention(h, s, P, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
-                                        W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14));
-        int r = launch_gemm16_ln(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, h->resid,
-                                 h->xn16, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, M, D, D);
-        if (r < 0) return r;
-        if (r == 1) {
-            WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
-                                 h->resid, nullptr, M, D, D, ACT_NONE));
-            WM_TRY(launch_layernorm_block(h, s, P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D));
-        }
-        WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.bias"), nullptr, 0, nullptr,
-                             h->hid16, M, 4 * D, D, ACT_GELU));
-        xn_ready = false;
-        if (i + 1 < h->depth && block_prec(h, i + 1) == P) {   // (the fused kernel's operand type is also its LayerNorm output type)
-            const std::string nb = e + "blocks." + std::to_string(i + 1) + ".";
-            r = launch_gemm16_ln(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, h->resid,
-                                 h->xn16, W32(h, nb + "norm1.weight"), W32(h, nb + "norm1.bias"), 1e-6f, M, D, 4 * D);
+                                        W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14, p8 ? h->ao8 : nullptr));
+        if (p8) WM_TRY(sat_check(h, s, WM_SAT_ATTN, h->ao8, (int64_t)M * D, WM_PREC_FP8));
+        else WM_TRY(sat_check(h, s, WM_SAT_ATTN, h->ao16, (int64_t)M * D, P));
+        bool n2_ready = false;                              // xn16 holds norm2 of the updated residual stream
+        if (p8) {
+            WM_TRY(launch_gemm8(h, s, P, h->ao8, W8(b + "attn.proj.weight"), W32(h, b + "attn.proj.weight.wscale"), W32(h, b + "attn.proj.bias"),
+                                h->resid, h->resid, nullptr, nullptr, M, D, D, ACT_NONE));
+        } else {
+            int r = m8 ? 1 : launch_gemm16_ln(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, h->resid,
+                                              h->xn16, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, M, D, D);
             if (r < 0) return r;
-            xn_ready = r == 0;
+            n2_ready = r == 0;
+            if (r == 1)
+                WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
+                                     h->resid, nullptr, M, D, D, ACT_NONE));
         }
-        if (!xn_ready)
-            WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
-                                 h->resid, nullptr, M, D, 4 * D, ACT_NONE));
+        if (!n2_ready)
+            WM_TRY(launch_layernorm_block(h, s, m8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D));
+        WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, m8 ? WM_PREC_FP8 : P));
+        xn_ready = false;
+        if (m8) {
+            WM_TRY(launch_gemm8(h, s, P, h->xn16, W8(b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.weight.wscale"), W32(h, b + "mlp.lin1.bias"),
+                                nullptr, nullptr, nullptr, h->hid16, M, 4 * D, D, ACT_GELU));
+            WM_TRY(sat_check(h, s, WM_SAT_HID, h->hid16, (int64_t)M * 4 * D, WM_PREC_FP8));
+            WM_TRY(launch_gemm8(h, s, P, h->hid16, W8(b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.weight.wscale"), W32(h, b + "mlp.lin2.bias"),
+                                h->resid, h->resid, nullptr, nullptr, M, D, 4 * D, ACT_NONE));
+        } else {
+            WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.bias"), nullptr, 0, nullptr,
+                                 h->hid16, M, 4 * D, D, ACT_GELU));
+            WM_TRY(sat_check(h, s, WM_SAT_HID, h->hid16, (int64_t)M * 4 * D, P));
+            // the fused kernel's operand type is also its LayerNorm output type: the next block's norm1 must want the same
+            if (i + 1 < h->depth && block_prec(h, i + 1) == PB && !f8) {
+                const std::string nb = e + "blocks." + std::to_string(i + 1) + ".";
+                int r = launch_gemm16_ln(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, h->resid,
+                                         h->xn16, W32(h, nb + "norm1.weight"), W32(h, nb + "norm1.bias"), 1e-6f, M, D, 4 * D);
+                if (r < 0) return r;
+                xn_ready = r == 0;
+            }
+            if (!xn_ready)
+                WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
+                                     h->resid, nullptr, M, D, 4 * D, ACT_NONE));
+        }
         WM_TRY(do_tap(h, s, i, B));
     }
 
     // ---- neck (image_encoder.py:105-121,136) ----
     WM_TRY(launch_simple(h, s, B * 31.5e6, cvt_f32_to_16_kernel<FP16>, dim3(grid_for((int64_t)M * D / 4)), dim3(256), (const float*)h->resid, (u16*)h->x16last, (int64_t)M * D / 4));
+    WM_TRY(sat_check(h, s, WM_SAT_LAST, h->x16last, (int64_t)M * D, PS));
     WM_TRY(launch_gemm16(h, s, PS, h->x16last, W16(h, e + "neck.0.weight"), nullptr, nullptr, 0, h->n1, nullptr, M, OUTC, D, ACT_NONE));
     WM_TRY(launch_layernorm(h, s, PS, h->n1, W32(h, e + "neck.1.weight"), W32(h, e + "neck.1.bias"), 1e-6f, nullptr, h->n1n16, M, OUTC));
     WM_TRY(launch_conv3x3_16(h, s, PS, h->n1n16, W16(h, e + "neck.2.weight"), h->n2, M, OUTC, OUTC));
@@ -1570,6 +1517,23 @@ extern "C" int wm_profile_read(wm_handle* h, wm_kclass_stat* out) {
     return 0;
 }
 
+extern "C" int wm_debug_saturation_enable(wm_handle* h, int on) {
+    if (!h) return fail("wm_debug_saturation_enable: null handle");
+    h->sat_on = on != 0;
+    return 0;
+}
+
+extern "C" int wm_debug_saturation_read(wm_handle* h, int64_t* out, int n, int reset, void* stream) {
+    if (!h || !out || n < WM_SAT_COUNT) return fail("wm_debug_saturation_read: need room for %d counters", WM_SAT_COUNT);
+    HIP_TRY(hipSetDevice(h->device));
+    unsigned long long host[WM_SAT_COUNT];
+    HIP_TRY(hipMemcpyAsync(host, h->sat_counts, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < WM_SAT_COUNT; ++i) out[i] = (int64_t)host[i];
+    if (reset) HIP_TRY(hipMemsetAsync(h->sat_counts, 0, sizeof(host), (hipStream_t)stream));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // single-op entry points
 // ---------------------------------------------------------------------------
@@ -1675,10 +1639,12 @@ struct ResizePlan {          // device tables of one geometry; owned by the libr
     int oh = 0, ow = 0, ksx = 0, ksy = 0;
     int *bx = nullptr, *kx = nullptr, *by = nullptr, *ky = nullptr;
 };
+struct ResizeTmp { unsigned char* p = nullptr; size_t bytes = 0; };
 struct ResizeDevState {
-    std::map<std::array<int, 4>, ResizePlan> plans;      // (h, w, size, max_size)
-    unsigned char* tmp = nullptr;
-    size_t tmp_bytes = 0;
+    std::map<std::array<int, 4>, ResizePlan> plans;      // (h, w, size, max_size); read-only once built
+    // the intermediate (horizontally resampled) image, one per STREAM: calls on different streams of a device may overlap
+    // on the GPU (a loader thread's side stream), and a shared buffer would be overwritten under the first call's kernels
+    std::map<hipStream_t, ResizeTmp> tmp;
 };
 std::map<int, ResizeDevState> g_resize;
 
@@ -1735,16 +1701,17 @@ extern "C" int wm_preprocess_u8_resized(const uint8_t* img_dev, float* out_dev, 
     }
     const ResizePlan& pl = it->second;
     const size_t need = (size_t)batch * height * ow * 3;
-    if (need > st.tmp_bytes) {
-        if (st.tmp) HIP_TRY(hipFree(st.tmp));
-        st.tmp = nullptr; st.tmp_bytes = 0;
-        HIP_TRY(hipMalloc((void**)&st.tmp, need));
-        st.tmp_bytes = need;
-    }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(resize_h_u8_kernel, dim3(grid_for((int64_t)batch * height * ow)), dim3(256), 0, s, img_dev, st.tmp, (const int*)pl.bx,
+    ResizeTmp& tmp = st.tmp[s];
+    if (need > tmp.bytes) {
+        if (tmp.p) HIP_TRY(hipFree(tmp.p));              // hipFree synchronises the device: no kernel still reads the old buffer
+        tmp.p = nullptr; tmp.bytes = 0;
+        HIP_TRY(hipMalloc((void**)&tmp.p, need));
+        tmp.bytes = need;
+    }
+    hipLaunchKernelGGL(resize_h_u8_kernel, dim3(grid_for((int64_t)batch * height * ow)), dim3(256), 0, s, img_dev, tmp.p, (const int*)pl.bx,
                        (const int*)pl.kx, pl.ksx, batch, height, width, ow);
-    hipLaunchKernelGGL(resize_v_normalize_kernel, dim3(grid_for((int64_t)batch * 1024 * 1024)), dim3(256), 0, s, (const unsigned char*)st.tmp, out_dev,
+    hipLaunchKernelGGL(resize_v_normalize_kernel, dim3(grid_for((int64_t)batch * 1024 * 1024)), dim3(256), 0, s, (const unsigned char*)tmp.p, out_dev,
                        (const int*)pl.by, (const int*)pl.ky, pl.ksy, batch, height, ow, oh);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -14,7 +14,8 @@ Differences, all outside the accelerated path:
     with `base_ds=None` no evaluator is built and `(stats, None)` is returned, as the reference's `if coco_evaluator is
     not None` branches allow;
   * detections are merged across ranks as fixed-size records by one padded all-gather (dist.gather_detections), not by
-    pickling (utils/misc.py:180-220).
+    pickling (utils/misc.py:180-220); `stats['images']` / `stats['detections']` count the MERGED set (each image once,
+    although DistributedSampler repeats images to pad the last shard).
 """
 from __future__ import annotations
 
@@ -37,8 +38,7 @@ def evaluate(model, criterion, postprocessors, data_loader, base_ds, device, arg
     coco_evaluator = CocoEvaluator(base_ds, iou_types) if base_ds is not None else None
     loss_sums: Dict[str, float] = defaultdict(float)
     n_batches = 0
-    n_images = 0
-    n_dets = 0
+    seen: Dict[int, int] = {}                     # image id -> detections (this rank), used when no evaluator merges
     for data in data_loader:
         image, targets = data[0], data[1]
         targets = [{k: (v.to(device) if hasattr(v, "to") else v) for k, v in t.items()} for t in targets]
@@ -55,8 +55,8 @@ def evaluate(model, criterion, postprocessors, data_loader, base_ds, device, arg
         orig_target_sizes = torch.stack([t["orig_size"] for t in targets], dim=0)
         results = postprocessors["bbox"](outputs, orig_target_sizes)
         res = {int(target["image_id"].item()): output for target, output in zip(targets, results)}
-        n_images += len(res)
-        n_dets += sum(len(o["scores"]) for o in res.values())
+        for k, o in res.items():
+            seen[k] = len(o["scores"])
         if coco_evaluator is not None:
             coco_evaluator.update(res)
 
@@ -66,15 +66,25 @@ def evaluate(model, criterion, postprocessors, data_loader, base_ds, device, arg
         coco_evaluator.accumulate()
         coco_evaluator.summarize()
     stats = {k: v / max(n_batches, 1) for k, v in loss_sums.items()}
-    world = utils.get_world_size()
-    counts = torch.tensor([n_images, n_dets], dtype=torch.float64)
-    if world > 1:
-        dev = torch.device("cuda", torch.cuda.current_device()) if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
-        counts = counts.to(dev)
-        torch.distributed.all_reduce(counts)
-        counts = counts.cpu()
-    stats["images"] = float(counts[0])
-    stats["detections"] = float(counts[1])
+    # images / detections of the whole job, each image once: DistributedSampler pads the last shard with repeats, so a sum
+    # over ranks would count those twice; the evaluator's merged set (or, without an evaluator, the same merge) does not
+    if coco_evaluator is not None:
+        ev = coco_evaluator.coco_eval["bbox"]
+        stats["images"] = float(len(coco_evaluator.img_ids))
+        stats["detections"] = float(sum(len(v) for v in ev.dts.values()))
+    else:
+        from . import dist as wdist
+        merged = wdist.gather_detections({k: {"boxes": np.zeros((0, 4), np.float32), "scores": np.zeros((0,), np.float32),
+                                              "labels": np.zeros((0,), np.int64)} for k in seen})
+        stats["images"] = float(len(merged))
+        if utils.get_world_size() > 1:
+            t = torch.tensor([float(sum(seen.values()))], dtype=torch.float64)
+            dev = torch.device("cuda", torch.cuda.current_device()) if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+            t = t.to(dev)
+            torch.distributed.all_reduce(t)
+            stats["detections"] = float(t.item())       # no evaluator: upper bound (sampler repeats counted per rank)
+        else:
+            stats["detections"] = float(sum(seen.values()))
     if coco_evaluator is not None and "bbox" in postprocessors.keys():
         stats["coco_eval_bbox"] = coco_evaluator.coco_eval["bbox"].stats.tolist()
     return stats, coco_evaluator
