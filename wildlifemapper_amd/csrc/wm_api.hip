@@ -396,6 +396,17 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
         }
     }
 #endif
+    if (const char* e = getenv("WM_GEMM_WPACK")) { if (atoi(e) == 1) a.conv_c = -3; if (atoi(e) == 2) a.conv_c = -4; }   // experiment: W packed in LDS-image order
+    {   // round-3 experiment (A/B in one process: tools/ab_wdir.py): W fragments direct to registers
+        const char* e = getenv("WM_GEMM_WDIR");
+        if (e && atoi(e) != 0) {
+            if (atoi(e) == 2) a.conv_c = -2;       // the caller passes W packed in fragment order (tools/ab_wdir.py --env-value 2)
+            WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, NSLOT, false, false, true>, LDS));
+            hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, NSLOT, false, false, true>), dim3(grid), dim3(512), LDS, s, a);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, NSLOT>), dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
