@@ -254,10 +254,24 @@ int wm_op_cvt_16_to_f32(const void* in_dev, float* out_dev, int64_t n, int preci
 
 /* C[M,N] = act(A[M,K] * W[N,K]^T + bias) (+ residual[(row % res_mod), N]).
  * A, W 16-bit; bias/residual fp32 or NULL; out_f32 and/or out_16 (either may be NULL).
- * act: 0 none, 1 GELU(erf), 2 ReLU.  res_mod <= 0 means M. */
+ * act: 0 none, 1 GELU(erf), 2 ReLU.  res_mod <= 0 means M.
+ *
+ * Operand layout flags, OR-ed into `act` (round 3).  The 256-row-tile kernel stages operands by 1 KiB LDS-DMA pieces
+ * (16 rows x 64 B of one 32-deep K-step); from a row-major operand a piece is 16 half lines, in "LDS-image order" it is 8
+ * whole 128-byte lines, which is worth 8 % of the GEMM time.  LDS-image order of a [rows][K] 16-bit matrix (rows % 16 == 0,
+ * K % 32 == 0): [rows / 16][K / 32][64 positions x 16 B], position l holding row l >> 2, 16-byte chunk (l & 3) ^ ((-(l >> 4)) & 3)
+ * of the 16 x 32 block (wm_op_pack16 produces it).  The engine packs every encoder GEMM weight at wm_finalize_weights and its
+ * LayerNorm / GELU epilogues write the activations that feed such a GEMM in this order; results are bit-identical to the
+ * row-major path.  Only shapes for which wm_op_gemm16_takes_packed() returns 1 accept the flags. */
+#define WM_GEMM_W_PACKED 0x1000     /* w_dev is in LDS-image order */
+#define WM_GEMM_A_PACKED 0x2000     /* a_dev is in LDS-image order */
+#define WM_GEMM_OUT_PACKED 0x4000   /* out_16_dev is written in LDS-image order (16-bit-only form: no fp32 output, no residual) */
+#define WM_LAYOUT_PACKED 0x100      /* wm_op_layernorm: OR into `precision`, 16-bit-only form: out_16_dev in LDS-image order */
 int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* bias_dev,
                  const float* residual_dev, int res_mod, float* out_f32_dev, void* out_16_dev,
                  int M, int N, int K, int act, int precision, void* stream);
+int wm_op_gemm16_takes_packed(int M, int N, int K);
+int wm_op_pack16(const void* in_dev, void* out_dev, int64_t rows, int K, void* stream);
 
 /* fp8 (OCP e4m3) GEMM of WM_PREC_FP8, gemm8.h: C = act((A W^T) * wscale[n] + bias[n]) (+ residual).
  * a [M,K] e4m3 (unit scale), w [N,K] e4m3, wscale [N] fp32; exactly one of: residual + out_f32 (+ out_16), out_8 (e4m3),

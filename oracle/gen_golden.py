@@ -60,11 +60,11 @@ def stats(t: torch.Tensor) -> np.ndarray:
                      t.min().item(), t.max().item()], dtype=np.float64)
 
 
-def load_synth(module: torch.nn.Module, prefix: str, seed: int = 0) -> dict:
+def load_synth(module: torch.nn.Module, prefix: str, seed: int = 0, profile: str = "baseline") -> dict:
     """Fill every tensor of module.state_dict() with synth.make_weight(prefix+name)."""
     sd = {}
     for k, v in module.state_dict().items():
-        sd[k] = torch.from_numpy(synth.make_weight(prefix + k, tuple(v.shape), seed))
+        sd[k] = torch.from_numpy(synth.make_weight(prefix + k, tuple(v.shape), seed, profile))
     module.load_state_dict(sd, strict=True)
     return {prefix + k: v for k, v in sd.items()}
 
@@ -244,14 +244,20 @@ def gen_e2e(out: str, model_type: str, n_tiles: int, first_tile: int) -> None:
           "kept:", [len(fx[f'pp{b}_nms_index']) for b in range(n_tiles)])
 
 
-def gen_e2e_outputs(out: str, model_type: str, n_tiles: int, first_tile: int, seed: int = 0, smooth: bool = False, content: int = 1024) -> None:
+def gen_e2e_outputs(out: str, model_type: str, n_tiles: int, first_tile: int, seed: int = 0, smooth: bool = False, content: int = 1024,
+                    profile: str = "baseline") -> None:
     """More tiles of the same model, outputs only (logits, boxes, the oracle-derived NMS list): the end-to-end tolerance is
     then checked on several inputs, not on one.  One tile per forward (bounded memory)."""
     enc, dec, pe = build_ref_model(model_type)
-    load_synth(enc, "image_encoder.", seed)
-    load_synth(dec, "mask_decoder.", seed)
-    load_synth(pe, "prompt_encoder.", seed)
-    fx = {"model_type": np.array(model_type), "first_tile": np.array(first_tile), "n_tiles": np.array(n_tiles), "weight_seed": np.array(seed)}
+    load_synth(enc, "image_encoder.", seed, profile)
+    load_synth(dec, "mask_decoder.", seed, profile)
+    load_synth(pe, "prompt_encoder.", seed, profile)
+    fx = {"model_type": np.array(model_type), "first_tile": np.array(first_tile), "n_tiles": np.array(n_tiles), "weight_seed": np.array(seed),
+          "profile": np.array(profile)}
+    peak = {}
+    if profile != "baseline":      # what the profile does to the activations: per-block max |x| and rms of the residual stream
+        for i, blk in enumerate(enc.blocks):
+            blk.register_forward_hook(lambda m, a, o, i=i: peak.__setitem__(i, (float(o.abs().max()), float(o.pow(2).mean().sqrt()))))
     lg, bx = [], []
     for t in range(n_tiles):
         x = torch.from_numpy(synth.make_batch(first_tile + t, 1, smooth=smooth))
@@ -266,6 +272,8 @@ def gen_e2e_outputs(out: str, model_type: str, n_tiles: int, first_tile: int, se
         print(f"[{model_type}] tile {first_tile + t}: reference forward {time.time() - t1:.1f}s")
         lg.append(res["pred_logits"].numpy())
         bx.append(res["pred_boxes"].numpy())
+        if peak:
+            fx[f"resid_max_rms_tile{t}"] = np.array([peak[i] for i in sorted(peak)], dtype=np.float32)
         det = O.detect(O.postprocess(res["pred_logits"], res["pred_boxes"], torch.tensor([[1024, 1024]]))[0])
         fx[f"pp{t}_nms_index"] = det["nms_index"].numpy()
     fx["pred_logits"], fx["pred_boxes"] = np.concatenate(lg, 0), np.concatenate(bx, 0)
@@ -276,6 +284,8 @@ def gen_e2e_outputs(out: str, model_type: str, n_tiles: int, first_tile: int, se
     if content < 1024:
         name = f"e2e_{model_type}_padded{content}.npz"
         fx["content"] = np.array(content)
+    if profile != "baseline":
+        name = f"e2e_{model_type}_{profile}.npz"
     np.savez_compressed(os.path.join(out, name), **fx)
     print(f"[{model_type}] wrote {name}", sum(v.nbytes for v in fx.values()) // 1024, "KiB kept:", [len(fx[f'pp{t}_nms_index']) for t in range(n_tiles)])
 
@@ -315,10 +325,10 @@ def gen_postprocess(out: str) -> None:
         lg, bx = torch.from_numpy(d["pred_logits"]), torch.from_numpy(d["pred_boxes"])
         cases.append((name[:-4], lg, bx, torch.tensor([[1024, 1024]] * lg.shape[0])))
     g = torch.Generator().manual_seed(19)
-    lg = torch.randn(3, 51, 7, generator=g) * 3
+    lg = torch.randn(3, 51, 8, generator=g) * 3
     bx = torch.rand(3, 51, 4, generator=g)
     cases.append(("random", lg, bx, torch.tensor([[640, 480], [1024, 768], [333, 1000]])))
-    lg0 = torch.zeros(1, 51, 7)
+    lg0 = torch.zeros(1, 51, 8)
     lg0[..., -1] = 12.0                                     # background wins everywhere: nothing above 0.05
     cases.append(("empty", lg0, torch.rand(1, 51, 4, generator=g), torch.tensor([[1024, 1024]])))
     fx["cases"] = np.array([c[0] for c in cases])
@@ -408,6 +418,8 @@ def main() -> None:
         gen_e2e_outputs(a.out, "vit_h", n_tiles=2, first_tile=0, seed=1)
     if a.only in ("all", "vit_h_smooth"):
         gen_e2e_outputs(a.out, "vit_h", n_tiles=2, first_tile=0, smooth=True)
+    if a.only in ("all", "vit_h_outlier"):
+        gen_e2e_outputs(a.out, "vit_h", n_tiles=2, first_tile=0, profile="outlier")
     if a.only in ("all", "vit_h_padded"):
         gen_e2e_outputs(a.out, "vit_h", n_tiles=2, first_tile=0, smooth=True, content=768)
 

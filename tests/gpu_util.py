@@ -37,15 +37,44 @@ def to16(x: torch.Tensor, prec: str) -> torch.Tensor:
     return out
 
 
-def gemm16(a16, w16, bias=None, residual=None, res_mod=0, act=0, prec="bf16", want32=True, want16=False):
+def gemm16(a16, w16, bias=None, residual=None, res_mod=0, act=0, prec="bf16", want32=True, want16=False, layout=0):
+    """layout: OR of N.GEMM_W_PACKED / GEMM_A_PACKED / GEMM_OUT_PACKED (operands in LDS-image order, see pack16)."""
     code, dt = PRECS[prec]
     M, K = a16.shape
     Nn = w16.shape[0]
     o32 = torch.empty((M, Nn), device=a16.device, dtype=torch.float32) if want32 else None
     o16 = torch.empty((M, Nn), device=a16.device, dtype=dt) if want16 else None
     N.check(N.lib().wm_op_gemm16(N.ptr(a16), N.ptr(w16), N.ptr(bias), N.ptr(residual), res_mod, N.ptr(o32), N.ptr(o16),
-                                 M, Nn, K, act, code, sp()))
+                                 M, Nn, K, act | layout, code, sp()))
     return o32, o16
+
+
+def pack16(t: torch.Tensor) -> torch.Tensor:
+    """[rows][K] 16-bit -> LDS-image order through the library's pack kernel (same shape, permuted content)."""
+    out = torch.empty_like(t)
+    N.check(N.lib().wm_op_pack16(N.ptr(t.contiguous()), N.ptr(out), t.shape[0], t.shape[1], sp()))
+    return out
+
+
+def _image_index(device):
+    l = torch.arange(64, device=device)
+    return l >> 2, (l & 3) ^ ((-(l >> 4)) & 3)
+
+
+def pack16_torch(t: torch.Tensor) -> torch.Tensor:
+    """The layout's definition restated with torch indexing (include/wm_hip.h): position l of a 16 x 32 block holds row
+    l >> 2, chunk (l & 3) ^ ((-(l >> 4)) & 3)."""
+    rows, K = t.shape
+    row, ch = _image_index(t.device)
+    return t.view(rows // 16, 16, K // 32, 4, 8)[:, row, :, ch, :].permute(1, 2, 0, 3).contiguous().view(rows, K)
+
+
+def unpack16_torch(p: torch.Tensor) -> torch.Tensor:
+    rows, K = p.shape
+    row, ch = _image_index(p.device)
+    out = torch.empty_like(p).view(rows // 16, 16, K // 32, 4, 8)
+    out[:, row, :, ch, :] = p.view(rows // 16, K // 32, 64, 8).permute(2, 0, 1, 3)
+    return out.view(rows, K)
 
 
 def gemm16_ln(a16, w16, bias, residual, gamma, beta, eps, prec="bf16"):
@@ -68,8 +97,10 @@ def gemm32(a, w, bias=None, residual=None, act=0):
     return out
 
 
-def layernorm(x, g, b, eps, prec="bf16", want32=True, want16=False):
+def layernorm(x, g, b, eps, prec="bf16", want32=True, want16=False, packed=False):
     code, dt = PRECS[prec]
+    if packed:
+        code |= N.LAYOUT_PACKED
     rows, Cc = x.shape
     o32 = torch.empty_like(x) if want32 else None
     o16 = torch.empty(x.shape, device=x.device, dtype=dt) if want16 else None

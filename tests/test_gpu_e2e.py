@@ -632,6 +632,43 @@ def test_vit_h_second_weight_seed_vs_reference_golden(golden_dir):
         m.load_state_dict(base, strict=True)
 
 
+def test_vit_h_outlier_weight_profile_vs_reference_golden(golden_dir):
+    """Activation outliers: synth profile "outlier" -- in blocks 5, 13, 21, 29 six LayerNorm gammas x50 in
+    norm1 / norm2, eight lin1 rows x30, two lin2 output channels x40 ("massive" channels that stay in the residual stream) --
+    against tests/golden/e2e_vit_h_outlier.npz (the reference's own modules with those weights on tiles 0, 1; oracle/gen_golden.py
+    --only vit_h_outlier).  fp16 operands, the default, must still meet north_star's 1e-3 on the logits with identical NMS
+    lists, and the saturation census must find no operand value at fp16's clamp; bf16's number is printed and bounded loosely."""
+    fx = np.load(os.path.join(golden_dir, "e2e_vit_h_outlier.npz"))
+    n, first = int(fx["n_tiles"]), int(fx["first_tile"])
+    assert str(fx["profile"]) == "outlier"
+    peak = fx["resid_max_rms_tile0"]
+    assert peak[:, 0].max() > 20 * peak[0, 1]              # the fixture's residual stream does carry outliers (max |x| vs block-0 rms)
+    m, _ = _model("vit_h", "fp16")
+    base = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    try:
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict("vit_h", 0, profile="outlier").items()}, strict=True)
+        x = torch.from_numpy(synth.make_batch(first, n)).to(G.dev())
+        for prec in ("fp16", "bf16"):
+            m._hub.set_precision(prec)
+            with torch.no_grad():
+                m.detect(x, torch.tensor([[1024, 1024]] * n))
+                m._hub.saturation_enable(True)
+                m._hub.saturation_read(reset=True)
+                out = m.detect(x, torch.tensor([[1024, 1024]] * n))
+                sat = m._hub.saturation_read(reset=True)
+                m._hub.saturation_enable(False)
+            lg = out["pred_logits"].cpu().numpy()
+            rec = split_records(out["records"].cpu())
+            errs = [float(np.linalg.norm(lg[t] - fx["pred_logits"][t]) / np.linalg.norm(fx["pred_logits"][t])) for t in range(n)]
+            same = [_nms_positions(rec, t) == fx[f"pp{t}_nms_index"].tolist() for t in range(n)]
+            print(f"[vit_h/{prec}/outlier profile] logits per tile " + " ".join(f"{e:.2e}" for e in errs) + f" NMS identical: {same}  clamped operands: {sat}")
+            assert all(v == 0 for v in sat.values()), sat
+            assert max(errs) < {"fp16": LOGIT_TOL["fp16"], "bf16": 5e-3}[prec], errs
+            assert prec != "fp16" or all(same), same
+    finally:
+        m.load_state_dict(base, strict=True)
+
+
 def test_input_pipeline_resize_bit_exact_vs_pil(golden_dir):
     """N1 with the val transform's resize (dataloader_coco.py:288): uint8 frame -> PIL-bilinear resample -> ToTensor ->
     Normalize -> zero-padded 1024^2 tile, on the GPU.  Integer work: bit-exact against (a) vectors PIL itself produced

@@ -195,6 +195,81 @@ def test_gemm16_dispatch_and_values_at_model_shapes(M, N, K, act, variant):
     assert G.rel_l2(o16.float(), y) < OUT16_TOL[prec]
 
 
+def test_pack16_is_the_documented_permutation():
+    """wm_op_pack16 (the kernel that packs the weights at wm_finalize_weights) against the layout's definition restated with
+    torch indexing, and the inverse."""
+    from wildlifemapper_amd import _native as Nn
+    t = torch.arange(48 * 96, device=G.dev(), dtype=torch.int32).to(torch.int16).view(48, 96)
+    p = G.pack16(t)
+    assert torch.equal(p, G.pack16_torch(t))
+    assert torch.equal(G.unpack16_torch(p), t)
+    w = G.to16(torch.randn(1280, 5120, device=G.dev()), "fp16")
+    assert torch.equal(G.unpack16_torch(G.pack16(w)), w)
+    with pytest.raises(RuntimeError, match="pack16"):
+        G.pack16(torch.zeros(24, 64, device=G.dev(), dtype=torch.float16))
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K,act,res", [(16384, 3840, 1280, 0, False),      # qkv: norm1 output packed, weight packed
+                                           (16384, 5120, 1280, 1, False),      # lin1 + GELU, output packed for lin2
+                                           (16384, 1280, 5120, 0, True),       # lin2: packed GELU hidden in, fp32 residual out
+                                           (16384, 1024, 1024, 2, False),      # 256-wide tile instance (ViT-L / HFC adaptor shapes)
+                                           (65536, 1280, 1280, 0, True)])      # proj at B = 16: packed weight only
+def test_gemm16_packed_operands_bit_identical(M, N, K, act, res, prec):
+    """Operands in LDS-image order (round 3: every DMA piece 8 whole lines instead of 16 half lines) put the same bytes in the
+    same LDS places, so every combination of packed W / packed A / packed 16-bit output must equal the row-major launch bit
+    for bit (and the packed output, un-permuted, the row-major output)."""
+    from wildlifemapper_amd import _native as Nn
+    dev = G.dev()
+    assert Nn.lib().wm_op_gemm16_takes_packed(M, N, K) == 1
+    a = G.to16(torch.randn(M, K, device=dev), prec)
+    w = G.to16(torch.randn(N, K, device=dev) / math.sqrt(K), prec)
+    bias = torch.randn(N, device=dev)
+    r = torch.randn(M, N, device=dev) if res else None
+    ap, wp = G.pack16(a), G.pack16(w)
+    base32, base16 = G.gemm16(a, w, bias, r, 0, act, prec, want32=res, want16=True)
+    y = a.float() @ w.float().t() + bias
+    y = {0: y, 1: O.gelu_erf(y), 2: torch.relu(y)}[act] + (r if res else 0)
+    assert G.rel_l2(base16.float(), y) < OUT16_TOL[prec]
+    for layout, aa, ww in ((Nn.GEMM_W_PACKED, a, wp), (Nn.GEMM_A_PACKED, ap, w), (Nn.GEMM_W_PACKED | Nn.GEMM_A_PACKED, ap, wp)):
+        o32, o16 = G.gemm16(aa, ww, bias, r, 0, act, prec, want32=res, want16=True, layout=layout)
+        assert torch.equal(o16, base16), layout
+        if res:
+            assert torch.equal(o32, base32), layout
+    if not res:
+        _, o16p = G.gemm16(ap, wp, bias, None, 0, act, prec, want32=False, want16=True,
+                           layout=Nn.GEMM_W_PACKED | Nn.GEMM_A_PACKED | Nn.GEMM_OUT_PACKED)
+        assert torch.equal(G.unpack16_torch(o16p), base16)
+    else:
+        with pytest.raises(RuntimeError, match="packed output"):
+            G.gemm16(a, w, bias, r, 0, act, prec, want32=True, want16=True, layout=Nn.GEMM_OUT_PACKED)
+
+
+def test_packed_layout_rejected_where_the_half_width_kernel_runs():
+    from wildlifemapper_amd import _native as Nn
+    dev = G.dev()
+    M, N, K = 4096, 1280, 5120                           # lin2 at B = 1: 64 wide tiles -> gemm16_v2<160>
+    assert Nn.lib().wm_op_gemm16_takes_packed(M, N, K) == 0
+    a = G.to16(torch.randn(M, K, device=dev), "fp16")
+    w = G.to16(torch.randn(N, K, device=dev), "fp16")
+    with pytest.raises(RuntimeError, match="row-major operands only"):
+        G.gemm16(a, w, None, None, 0, 0, "fp16", layout=Nn.GEMM_W_PACKED)
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("C", [1280, 1024, 768])
+def test_layernorm_packed_output(prec, C):
+    """The blocks' LayerNorm writing its 16-bit output in LDS-image order (the A operand of qkv / lin1): the same values,
+    permuted."""
+    dev = G.dev()
+    x = torch.randn(8192, C, device=dev) * 2 + 0.3
+    g, b = 1 + 0.1 * torch.randn(C, device=dev), 0.1 * torch.randn(C, device=dev)
+    _, plain = G.layernorm(x, g, b, 1e-6, prec, want32=False, want16=True)
+    _, packed = G.layernorm(x, g, b, 1e-6, prec, want32=False, want16=True, packed=True)
+    assert torch.equal(G.unpack16_torch(packed), plain)
+    assert torch.equal(packed, G.pack16(plain))
+
+
 def test_gemm16_kernels_agree_bitwise():
     """A tile's result must not depend on which GEMM kernel its batch size selects (batch-invariant
     bit for bit): the same rows through the half-width kernel (M = 4096) and through the staggered 256 x 320 kernel

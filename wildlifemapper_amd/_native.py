@@ -21,6 +21,7 @@ FLAG_CONF, FLAG_SCORE, FLAG_NMS, FLAG_MERGED = 1, 2, 4, 8
 CFG_FUSE_LN = 1
 ABI_VERSION = 2            # include/wm_hip.h WM_ABI_VERSION this binding was written for
 FP8_QKV, FP8_PROJ, FP8_MLP, FP8_ALL = 1, 2, 4, 7
+GEMM_W_PACKED, GEMM_A_PACKED, GEMM_OUT_PACKED, LAYOUT_PACKED = 0x1000, 0x2000, 0x4000, 0x100
 SAT_NAMES = ("layernorm_out", "qkv", "attention_out", "mlp_hidden", "last_block_16")
 
 
@@ -71,6 +72,8 @@ SYMBOLS = {
     "wm_op_cvt_f32_to_16": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_cvt_16_to_f32": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_gemm16": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm_op_gemm16_takes_packed": (_I, [_I, _I, _I]),
+    "wm_op_pack16": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_gemm16_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
     "wm_op_gemm8": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm_op_cvt_f32_to_fp8": (_I, [_P, _P, _L, _P]),

@@ -145,7 +145,7 @@ __device__ __forceinline__ void softmax_pv(SoftmaxState<AttnGeom<HD>::NDT>& st, 
     for (int ks = 0; ks < 2 * NT; ++ks) {
         typename T::vec8 pb;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pb[j] = T::from_f32(s[ks >> 1][8 * (ks & 1) + j]);
+        for (int j = 0; j < 8; ++j) pb[j] = T::from_f32_bounded(s[ks >> 1][8 * (ks & 1) + j]);     // P <= 2^RESCALE_THR
 #pragma unroll
         for (int dt = 0; dt < G::NDT; ++dt) {
             const char* p = sV + (16 * ks) * G::VS + dt * 64 + v_lane_off;
@@ -202,7 +202,7 @@ __device__ __forceinline__ void store_out(SoftmaxState<AttnGeom<HD>::NDT>& st, u
                 } else {
                     typename T::vec4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = T::from_f32(st.o[dt][4 * rg + j] * inv);
+                    for (int j = 0; j < 4; ++j) o[j] = T::from_f32_bounded(st.o[dt][4 * rg + j] * inv);     // a convex combination of V rows
                     *(typename T::vec4*)(out_row + d) = o;
                 }
             }

@@ -57,6 +57,9 @@ struct Gemm16Args {
     // row tiles per group of the grouped tile order (gemm16_v5.h; 0 = G16_GROUP_M): a group's row tiles x all column tiles
     // are consecutive tile ids, so group_m * tilesN ~ the 32 workgroups co-resident on an XCD keeps each A panel to one XCD
     int group_m;
+    // gemm16_v5.h only: W / A stored in LDS-image order ([rows / 16][K / 32][64 x 16 B], pack16_lds_image_kernel); out_packed:
+    // the 16-bit output is written in that order (it is the next GEMM's A operand; N % 32 == 0)
+    int w_packed, a_packed, out_packed;
 };
 
 template <class T>

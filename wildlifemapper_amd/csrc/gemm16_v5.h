@@ -36,12 +36,16 @@ namespace wm {
 // LNF: the fp32-residual epilogue also LayerNorms the finished rows (see its code and Gemm16Args::ln_*).
 // (A persistent instance -- one workgroup per CU walking its tiles and prefetching the next tile's first K-steps during the
 // epilogue -- was built in round 2, bit-identical and 7-15 % slower: tools/experiments/gemm16_v5_persist.h)
-// WDIR (round 3 experiment): the W fragments do not go through the LDS ring.  Each wave loads its NT
-// fragments of K-step s straight into the fragment registers (global_load_dwordx4, lane = (n = lane & 15, k-group = lane >> 4),
-// W is small and L2-resident) at the start of its load interval of step s and waits for them (counted vmcnt: register
-// loads and LDS-DMA share the in-order counter) at the start of its MFMA interval, one barrier later; only the A tile (2
-// pieces per wave and step) rides the ring.  Same accumulation order -> bit-identical results.
-template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false, bool WDIR = false>
+// Operand layout (round 3).  A DMA piece is 1 KiB of LDS: 16 rows x 64 B of one K-step.  Read from a row-major operand
+// it is 16 separate half lines (64 B each, a row apart); the fabric moves 128-byte lines, and the half-line pieces cost the
+// loop 8 % (A/B in one process, profiles/r3_dev/gemm_ab_*pack*).  With `w_packed` / `a_packed` the operand is stored in
+// LDS-IMAGE ORDER, [rows / 16][K / 32][64 x 16 B]: position l of a piece holds row l >> 2, chunk (l & 3) ^ ((-(l >> 4)) & 3)
+// -- the swizzle already applied -- so a piece is 8 whole lines and the per-lane source offset is lane * 16.  Weights are
+// packed once at wm_finalize_weights (pack16_lds_image_kernel); activations are written in this order by their producers
+// (LayerNorm, the GELU epilogue below with `out_packed`).  Same bytes in the same LDS places: results are bit-identical.
+// (Also measured in round 3 and archived, tools/experiments/gemm16_v5_wdirect.h: W fragments loaded straight into registers,
+// bypassing the ring: 1.44x slower from row-major W, 1.07x slower from fragment-packed W.)
+template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     using C = G3<BN, 4>;
     constexpr int AHEAD = NSLOT - 1;                       // K-steps of DMA in flight
@@ -93,20 +97,17 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
 #pragma unroll
         for (int i = 0; i < C::A_PIECES; ++i) {
             const int seg = wave * C::A_PIECES + i;
-            // res_mod == -7 (experiment): A pre-packed in LDS-image order [M / 16][K / 32][1 KiB piece]
-            const bool a_packed = p.conv_c <= -3 && (p.conv_c & 1) == 0;       // -4: A and W packed
+            const bool a_packed = p.a_packed != 0;
             const char* base = a_packed ? sgpr_ptr(Ab + ((size_t)((m0 + seg * 16) / 16) * (size_t)ns + (size_t)s) * 1024)
                                         : sgpr_ptr(Ab + (size_t)(m0 + seg * 16) * row_bytes + (size_t)s * 64);
             __builtin_amdgcn_global_load_lds(base + (a_packed ? (unsigned)lane * 16u : lane_off), WM_LDS_PTR(smem + slot * C::STAGE + seg * 1024), 16, 0, 0);
         }
-        if constexpr (WDIR) return;
 #pragma unroll
         for (int i = 0; i < C::W_LO + (EXTRA ? 1 : 0); ++i) {
             const int seg = i < C::W_LO ? wave * C::W_LO + i : C::WAVES * C::W_LO + wave;
-            // conv_c == -3 (experiment): W pre-packed in LDS-image order [N / 16][K / 32][1 KiB piece]: a piece is 8 whole 128-byte lines
-            const char* base = p.conv_c <= -3 ? sgpr_ptr(Wb + ((size_t)((n0 + seg * 16) / 16) * (size_t)ns + (size_t)s) * 1024)
+            const char* base = p.w_packed ? sgpr_ptr(Wb + ((size_t)((n0 + seg * 16) / 16) * (size_t)ns + (size_t)s) * 1024)
                                               : sgpr_ptr(Wb + (size_t)(n0 + seg * 16) * row_bytes + (size_t)s * 64);
-            __builtin_amdgcn_global_load_lds(base + (p.conv_c <= -3 ? (unsigned)lane * 16u : lane_off), WM_LDS_PTR(smem + slot * C::STAGE + C::A_BYTES + seg * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(base + (p.w_packed ? (unsigned)lane * 16u : lane_off), WM_LDS_PTR(smem + slot * C::STAGE + C::A_BYTES + seg * 1024), 16, 0, 0);
         }
     };
     auto stage = [&](int slot, int s, auto extra_tag) { stage_at(slot, s, extra_tag, m0, n0); };
@@ -122,39 +123,11 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         const char* sS = smem + slot * C::STAGE;
         const int rd_a = rd_a_k, rd_w = rd_w_k;
         af[0] = *(const typename T::vec8*)(sS + rd_a);
-        if constexpr (!WDIR) {
 #pragma unroll
-            for (int i = 0; i < C::NT; ++i) wf[i] = *(const typename T::vec8*)(sS + rd_w + i * 1024);
-        }
+        for (int i = 0; i < C::NT; ++i) wf[i] = *(const typename T::vec8*)(sS + rd_w + i * 1024);
 #pragma unroll
         for (int i = 1; i < C::MT; ++i) af[i] = *(const typename T::vec8*)(sS + rd_a + i * 1024);
     };
-    // WDIR: this wave's W fragments of K-step s, straight from global memory (L2) into the fragment registers
-    // conv_c == -2 (experiment): W is pre-packed in fragment order [N / 16][K / 32][lane][8]: one fragment = 1 KiB contiguous
-    const bool w_packed = WDIR && p.conv_c == -2;
-    const unsigned w_lane_off = w_packed ? (unsigned)lane * 16u : (unsigned)fr * (unsigned)(K * 2) + (unsigned)(fq << 4);
-    auto w_issue = [&](int s) {
-        if constexpr (WDIR) {
-#pragma unroll
-            for (int i = 0; i < C::NT; ++i) {
-                const char* base = w_packed ? sgpr_ptr(Wb + ((size_t)((n0 + wc * C::WCOLS) / 16 + i) * (size_t)ns + (size_t)s) * 1024)
-                                            : sgpr_ptr(Wb + (size_t)(n0 + wc * C::WCOLS + i * 16) * row_bytes + (size_t)s * 64);
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wf[i]) : "v"(w_lane_off), "s"(base) : "memory");
-            }
-        }
-    };
-    // WDIR: the fragments issued by w_issue have arrived; `younger` = VMEM operations issued after them that may stay in flight
-    auto w_wait = [&](bool a_in_flight) {
-        if constexpr (WDIR) {
-            // the counted wait carries no register operands (a "+v" tie in each arm of the branch makes the two arms define
-            // different values, and hipcc then copies the fragment registers BEFORE one of the waits); ONE tie after the join
-            if (a_in_flight) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if constexpr (C::NT == 5) asm volatile("" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4])::"memory");
-            else asm volatile("" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3])::"memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    static_assert(!WDIR || (C::A_PIECES == 2 && (C::NT == 5 || C::NT == 4) && NSLOT == 3 && !LNF && !DBG), "WDIR instance");
     auto mfmas = [&]() {
 #pragma unroll
         for (int mi = 0; mi < C::MT; ++mi)
@@ -165,15 +138,6 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     auto dec = [](int v) { return v == 0 ? NSLOT - 1 : v - 1; };
     constexpr int RP_CPR = BN * 4 / 16, RP_PW = RP_CPR / 16;       // residual tile: 16-byte chunks per row; DMA pieces per wave and pass
     auto wait_step = [&](int s, auto extra_tag) {          // this wave's pieces of step s have landed
-        if constexpr (WDIR) {
-            // in issue order behind the A pieces of step s: (waves 4-7 only) the NT fragment loads of step s - 1, still
-            // unwaited, then the A pieces of step s + 1
-            if (wr == 0) { if (s + 1 < ns) wait_vmcnt<C::A_PIECES>(); else wait_vmcnt<0>(); }
-            else if (s == 0) wait_vmcnt<C::A_PIECES>();
-            else if (s + 1 < ns) wait_vmcnt<C::NT + C::A_PIECES>();
-            else wait_vmcnt<C::NT>();
-            return;
-        }
         constexpr int P = C::P_LO + (decltype(extra_tag)::value ? 1 : 0);
         if (dbg_noissue) { wait_vmcnt<0>(); return; }
         if constexpr (AHEAD == 3) {
@@ -239,13 +203,11 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             barrier();                                      // X_s
             if constexpr (DBG) { if (s == 0) { wt1 = wall_clock64(); mt1 = __builtin_readcyclecounter(); } }
             mark(s, 2);
-            w_issue(s);
             read_frags(slot);
             if (s + AHEAD < ns) stage(dec(slot), s + AHEAD, EX{});
             mark(s, 3);
             barrier();                                      // Y_s
             mark(s, 4);
-            w_wait(s + AHEAD < ns);
             mfmas();
             mark(s, 5);
             slot = inc(slot);
@@ -264,17 +226,15 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             mark(s, 1);
             barrier();                                      // X_s
             mark(s, 2);
-            if (s > 0) { w_wait(s + 1 < ns); mfmas(); }     // step s-1 (its fragment loads precede the A pieces of step s+1)
+            if (s > 0) mfmas();                             // step s-1
             mark(s, 3);
             barrier();                                      // Y_s
             mark(s, 4);
-            w_issue(s);
             read_frags(slot);
             if (s + AHEAD < ns) stage(dec(slot), s + AHEAD, EX{});
             mark(s, 5);
             slot = inc(slot);
         }
-        w_wait(false);
         mfmas();                                            // step ns-1
     }
 
@@ -439,12 +399,28 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
                 }
             epi_sync();
             if constexpr (DBG) { if (q < 2) we[1 + 2 * q] = wall_clock64(); }
+            if (p.out_packed) {
+                // the output is the next GEMM's A operand: written in LDS-image order.  A wave moves one 16 x 32 tile (1 KiB,
+                // contiguous in memory) per iteration: lane l = position l of the piece = row l >> 2, logical chunk
+                // (l & 3) ^ ((-(l >> 4)) & 3) of the staged rows.
+                constexpr int KT = BN / 32;
+                static_assert((ROWS / 16) * KT * 64 == ROWS * CPR, "packed epilogue");
+#pragma unroll
+                for (int it = 0; it < ROWS * CPR / 512; ++it) {
+                    const int tile = it * 8 + wave, rt = tile / KT, kt = tile - rt * KT;
+                    const int l = tid & 63, lc = (l & 3) ^ ((0 - (l >> 4)) & 3);
+                    const f32x4 v = *(const f32x4*)(smem + EPI_BASE + (rt * 16 + (l >> 2)) * ROWB + (kt * 4 + lc) * 16);
+                    const int mt = (m0 + (rt / MTP) * 128 + q * MTP * 16 + (rt % MTP) * 16) >> 4;
+                    if (!dbg_nostore) *(f32x4*)((char*)p.out16 + ((size_t)mt * (p.N >> 5) + (n0 >> 5) + kt) * 1024 + l * 16) = v;
+                }
+            } else {
 #pragma unroll
             for (int it = 0; it < ROWS * CPR / 512; ++it) {
                 const int c = it * 512 + tid, r = c / CPR, ch = c - r * CPR;
                 const int m = m0 + (r / (MTP * 16)) * 128 + q * MTP * 16 + (r % (MTP * 16));
                 const f32x4 v = *(const f32x4*)(smem + EPI_BASE + r * ROWB + ch * 16);
                 if (!dbg_nostore) *(f32x4*)((char*)p.out16 + ((size_t)m * p.N + n0) * 2 + ch * 16) = v;
+            }
             }
             if constexpr (DBG) { if (q < 2) we[2 + 2 * q] = wall_clock64(); }
             if (q + 1 < C::MT / MTP) epi_sync();

@@ -83,10 +83,29 @@ __device__ __forceinline__ void store4_as(void* base, int64_t elem, const f32x4&
     }
 }
 
+// Element index of (row, col) of a [rows][C] 16-bit operand stored in LDS-image order (gemm16_v5.h "Operand layout"):
+// [rows / 16][C / 32][64 positions x 8 elements], position = (row % 16) * 4 + (chunk ^ ((-((row % 16) >> 2)) & 3)),
+// chunk = (col % 32) / 8.  rows % 16 == 0, C % 32 == 0.
+__device__ __forceinline__ int64_t lds_image_index(int64_t row, int col, int C) {
+    const int r = (int)(row & 15), cw = col & 31;
+    const int pos = r * 4 + ((cw >> 3) ^ ((0 - (r >> 2)) & 3));
+    return ((row >> 4) * (C >> 5) + (col >> 5)) * 512 + pos * 8 + (cw & 7);
+}
+
+// row-major [rows][K] 16-bit -> LDS-image order (weights at wm_finalize_weights; tests).  One thread per 16-byte chunk.
+__global__ __launch_bounds__(256) void pack16_lds_image_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t rows, int K) {
+    const int64_t n16 = rows * (K / 8);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / (K / 8);
+        const int col = (int)(i - row * (K / 8)) * 8;
+        out[lds_image_index(row, col, K) >> 3] = in[i];
+    }
+}
+
 template <class T, int BN>
 __global__ __launch_bounds__(256) void layernorm_tiled_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, u16* __restrict__ out16,
-                                                              int64_t rows, int C) {
+                                                              int64_t rows, int C, int packed) {
     constexpr int CPT = BN / 64;                       // 16-byte chunks per lane (BN / 4 per tile over 16 lanes)
     const int lane = threadIdx.x & 63, k = lane >> 4, l16 = lane & 15;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -116,7 +135,8 @@ __global__ __launch_bounds__(256) void layernorm_tiled_kernel(const float* __res
         f32x4 y;
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = ln_apply(v[kk][j], mean, rstd, g[j], b[j]);
-        store4_as<T>(out16, row * C + c0, y);
+        // packed: the output is the A operand of a gemm16_v5 launch and is written in LDS-image order (16-bit types only)
+        store4_as<T>(out16, packed ? lds_image_index(row, c0, C) : row * C + c0, y);
     }
 }
 

@@ -225,6 +225,7 @@ struct wm_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // name -> shape
     std::map<std::string, HostW> staged;
     std::map<std::string, uint16_t*> w16;
+    std::map<std::string, uint16_t*> w16p;  // the same weights in LDS-image order (gemm16_v5.h "Operand layout"), for the 256-row-tile kernels
     std::map<std::string, uint8_t*> w8;     // WM_PREC_FP8: e4m3 weights of the blocks' GEMMs; their per-channel scales live in w32[name + ".wscale"]
     uint8_t* ao8 = nullptr;                 // attention output as e4m3 (A operand of proj)
     std::map<std::string, float*> w32;
@@ -396,17 +397,6 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
         }
     }
 #endif
-    if (const char* e = getenv("WM_GEMM_WPACK")) { if (atoi(e) == 1) a.conv_c = -3; if (atoi(e) == 2) a.conv_c = -4; }   // experiment: W packed in LDS-image order
-    {   // round-3 experiment (A/B in one process: tools/ab_wdir.py): W fragments direct to registers
-        const char* e = getenv("WM_GEMM_WDIR");
-        if (e && atoi(e) != 0) {
-            if (atoi(e) == 2) a.conv_c = -2;       // the caller passes W packed in fragment order (tools/ab_wdir.py --env-value 2)
-            WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, NSLOT, false, false, true>, LDS));
-            hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, NSLOT, false, false, true>), dim3(grid), dim3(512), LDS, s, a);
-            HIP_TRY(hipGetLastError());
-            return 0;
-        }
-    }
     hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, NSLOT>), dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -498,12 +488,15 @@ int launch_gemm16v5_ln_t(wm_handle* h, hipStream_t s, Gemm16Args a) {
 // out32 = residual + A W^T + bias (residual may alias out32), out16 = LayerNorm(out32 rows).  Returns 1 (and launches
 // nothing) when the shape cannot be fused; the caller then runs the GEMM and the LayerNorm kernel separately.
 int launch_gemm16_ln(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias, const float* res,
-                     float* out32, void* out16, const float* gamma, const float* beta, float eps, int M, int N, int K) {
+                     float* out32, void* out16, const float* gamma, const float* beta, float eps, int M, int N, int K,
+                     const void* Wp = nullptr, int a_packed = 0) {
     const bool off = h && !(h->cfg.flags & WM_CFG_FUSE_LN);          // engine: opt-in; the single-op entry always fuses
     const int bn = ln_fuse_bn(M, N, K);
     if (off || !bn || !res || !out32 || !out16 || !gamma || !beta) return 1;
     constexpr int dbg_bits = 0;
     Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, 0, ACT_NONE | dbg_bits, 0, nullptr, gamma, beta, eps, nullptr, nullptr, 0};
+    if (Wp) { a.W = (const u16*)Wp; a.w_packed = 1; }
+    a.a_packed = a_packed;
     if (bn == 320) return prec == WM_PREC_FP16 ? launch_gemm16v5_ln_t<FP16, 320>(h, s, a) : launch_gemm16v5_ln_t<BF16, 320>(h, s, a);
     return prec == WM_PREC_FP16 ? launch_gemm16v5_ln_t<FP16, 256>(h, s, a) : launch_gemm16v5_ln_t<BF16, 256>(h, s, a);
 }
@@ -527,23 +520,39 @@ static double round_eff(long tiles, long slots) { return (double)tiles / (double
 
 #define WM_BY_PREC(call_bf16, call_fp16) (prec == WM_PREC_FP16 ? (call_fp16) : (call_bf16))
 
+// The staggered 256 x 320 / 256 x 256 kernel (gemm16_v5.h) serves the shape: the only kernel that reads operands in
+// LDS-image order and writes its 16-bit output in it.  Few tiles (one or two image tiles per call): the half-width
+// 256 x 160 / 128 kernel fills more CUs; cost model from tools/gemm_bench.py --batch 1: rounds of 256 workgroups x (1.0 | 0.6) per tile.
+static bool gemm16_takes_v5(int M, int N, int K) {
+    if (M <= 0 || M % 256 || K % G16_BK || K / 32 < 2) return false;
+    auto prefer_half = [&](int bn) {
+        const long t = (long)(M / 256) * (N / bn);
+        return (double)((2 * t + 255) / 256) * 0.6 < (double)((t + 255) / 256);
+    };
+    if (N % 320 == 0) return !prefer_half(320);
+    if (N % 256 == 0) return !prefer_half(256);
+    return false;
+}
+
+// Wp: the weight in LDS-image order (or null); a_packed / out_packed: A is / the 16-bit output shall be in that order.  Packed
+// operands exist only for the gemm16_v5 kernel: the caller asks gemm16_takes_v5 first, a mismatch is an error.
 int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias,
-                  const float* res, int res_mod, float* out32, void* out16, int M, int N, int K, int act) {
+                  const float* res, int res_mod, float* out32, void* out16, int M, int N, int K, int act,
+                  const void* Wp = nullptr, int a_packed = 0, int out_packed = 0) {
     if (M <= 0 || N <= 0 || K <= 0 || M % G16_BM || N % G16_BN || K % G16_BK)
         return fail("gemm16: shape M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, G16_BM, G16_BN, G16_BK);
     if (!out32 && !out16) return fail("gemm16: no output");
     Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act, 0, nullptr};
+    if (gemm16_takes_v5(M, N, K)) {         // staggered wave groups (gemm16_v5.h)
+        if (Wp) { a.W = (const u16*)Wp; a.w_packed = 1; }
+        a.a_packed = a_packed;
+        a.out_packed = out_packed;
+        if (out_packed && (out32 || res || !out16)) return fail("gemm16: a packed output is the 16-bit-only form (no fp32 output, no residual)");
+        if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320>(h, s, a)), (launch_gemm16v5_t<FP16, 320>(h, s, a)));
+        return WM_BY_PREC((launch_gemm16v5_t<BF16, 256>(h, s, a)), (launch_gemm16v5_t<FP16, 256>(h, s, a)));
+    }
+    if (a_packed || out_packed) return fail("gemm16: M=%d N=%d K=%d runs on a half-width kernel, which takes row-major operands only", M, N, K);
     if (M % 256 == 0) {
-        if (K / 32 >= 2) {      // staggered wave groups (gemm16_v5.h)
-            // Few tiles (one or two image tiles per call): the half-width 256 x 160 / 128 kernel fills more CUs.  Cost
-            // model from tools/gemm_bench.py --batch 1: rounds of 256 workgroups x (1.0 | 0.6) per tile.
-            auto prefer_half = [&](int bn) {
-                const long t = (long)(M / 256) * (N / bn);
-                return (double)((2 * t + 255) / 256) * 0.6 < (double)((t + 255) / 256);
-            };
-            if (N % 320 == 0 && !prefer_half(320)) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320>(h, s, a)), (launch_gemm16v5_t<FP16, 320>(h, s, a)));
-            if (N % 320 != 0 && N % 256 == 0 && !prefer_half(256)) return WM_BY_PREC((launch_gemm16v5_t<BF16, 256>(h, s, a)), (launch_gemm16v5_t<FP16, 256>(h, s, a)));
-        }
         // half-width tiles: 256 x 160 where N allows and it fills the last round at least as well as 256 x 128
         const bool can160 = N % 160 == 0;
         const bool use160 = can160 && (N % 320 == 0 || round_eff((long)(M / 256) * (N / 160), 256) >= round_eff((long)(M / 256) * (N / 128), 256) - 1e-9);
@@ -672,21 +681,23 @@ int launch_layernorm(wm_handle* h, hipStream_t s, int prec, const float* x, cons
 // LayerNorm of the transformer blocks (norm1 / norm2, 16-bit output): column-tiled statistics, bit-identical to the
 // LayerNorm fused into the residual GEMMs (launch_gemm16_ln), so results do not depend on which of the two ran.
 int launch_layernorm_block(wm_handle* h, hipStream_t s, int prec, const float* x, const float* g, const float* b, float eps,
-                           void* out16, int64_t rows, int C) {
+                           void* out16, int64_t rows, int C, int packed = 0) {
     const int bn = C % 320 == 0 ? 320 : (C % 256 == 0 ? 256 : 0);
     if ((!bn || C / bn > 4) && prec == WM_PREC_FP8) return fail("layernorm: C=%d has no e4m3 form", C);
+    if (packed && (prec == WM_PREC_FP8 || !bn || C / bn > 4 || rows % 16 || C % 32))
+        return fail("layernorm: no LDS-image-order output for rows=%lld C=%d precision %d", (long long)rows, C, prec);
     if (!bn || C / bn > 4) return launch_layernorm(h, s, prec, x, g, b, eps, nullptr, out16, rows, C);
     const dim3 grid((unsigned)((rows + 3) / 4));
     Bracket br(h, s, WM_KCLASS_LAYERNORM, 0.0, (double)rows * C * (prec == WM_PREC_FP8 ? 5.0 : 6.0));
     if (prec == WM_PREC_FP8) {
-        if (bn == 320) hipLaunchKernelGGL((layernorm_tiled_kernel<FP8, 320>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
-        else hipLaunchKernelGGL((layernorm_tiled_kernel<FP8, 256>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
+        if (bn == 320) hipLaunchKernelGGL((layernorm_tiled_kernel<FP8, 320>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C, 0);
+        else hipLaunchKernelGGL((layernorm_tiled_kernel<FP8, 256>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C, 0);
     } else if (bn == 320) {
-        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((layernorm_tiled_kernel<FP16, 320>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
-        else hipLaunchKernelGGL((layernorm_tiled_kernel<BF16, 320>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
+        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((layernorm_tiled_kernel<FP16, 320>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C, packed);
+        else hipLaunchKernelGGL((layernorm_tiled_kernel<BF16, 320>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C, packed);
     } else {
-        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((layernorm_tiled_kernel<FP16, 256>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
-        else hipLaunchKernelGGL((layernorm_tiled_kernel<BF16, 256>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C);
+        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((layernorm_tiled_kernel<FP16, 256>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C, packed);
+        else hipLaunchKernelGGL((layernorm_tiled_kernel<BF16, 256>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C, packed);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1093,6 +1104,8 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
     for (auto& kv : h->staged) {
         auto i16 = h->w16.find(kv.first);
         if (i16 != h->w16.end()) { hipFree(i16->second); for (auto& a : h->allocs) if (a == i16->second) a = nullptr; h->w16.erase(i16); }
+        auto i16p = h->w16p.find(kv.first);
+        if (i16p != h->w16p.end()) { hipFree(i16p->second); for (auto& a : h->allocs) if (a == i16p->second) a = nullptr; h->w16p.erase(i16p); }
         auto i32 = h->w32.find(kv.first);
         if (i32 != h->w32.end()) { hipFree(i32->second); for (auto& a : h->allocs) if (a == i32->second) a = nullptr; h->w32.erase(i32); }
         auto i8 = h->w8.find(kv.first);
@@ -1125,6 +1138,16 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
             WM_TRY(upload8(h, name, w.data.data(), (size_t)w.shape[0], n / (size_t)w.shape[0]));
         } else if (is_gemm_w) {
             WM_TRY(upload16(h, name, w.data.data(), n));
+            // second copy in LDS-image order for the 256-row-tile kernel (row-major stays for the half-width kernels that
+            // small batches take): [N][K] with N % 16 == 0 and K % 32 == 0 (every GEMM weight of the encoder)
+            const int64_t rows = w.shape[0], cols = (int64_t)n / rows;
+            if (rows % 16 == 0 && cols % 32 == 0) {
+                uint16_t* dp = nullptr;
+                WM_TRY(dalloc(h, &dp, n * 2));
+                hipLaunchKernelGGL(pack16_lds_image_kernel, dim3(grid_for((int64_t)n / 8)), dim3(256), 0, 0, (const uint4*)h->w16.at(name), (uint4*)dp, rows, (int)cols);
+                HIP_TRY(hipGetLastError());
+                h->w16p[name] = dp;
+            }
         } else {
             WM_TRY(upload32(h, name, w.data.data(), n));
         }
@@ -1147,6 +1170,7 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
         HIP_TRY(hipMemcpy(h->kpe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
     }
     (void)D;
+    HIP_TRY(hipDeviceSynchronize());        // the pack launches above
     h->staged.clear();
     h->finalized = true;
     return 0;
@@ -1168,6 +1192,7 @@ int check_ready(wm_handle* h, int batch, const char* fn, bool need_enc, bool nee
 }
 
 const uint16_t* W16(wm_handle* h, const std::string& n) { return h->w16.at(n); }
+const uint16_t* W16P(wm_handle* h, const std::string& n) { auto it = h->w16p.find(n); return it == h->w16p.end() ? nullptr : it->second; }
 const float* W32(wm_handle* h, const std::string& n) { return h->w32.at(n); }
 
 int do_tap(wm_handle* h, hipStream_t s, int which, int batch, const float* src = nullptr) {
@@ -1212,34 +1237,36 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     WM_TRY(launch_simple(h, s, B * 6.3e6, patchify_kernel<FP16>, dim3(grid_for((int64_t)B * 1024 * 256)), dim3(256), hfc, (u16*)h->h16, B, 1));
     // t = patch_embed(x) + pos_embed  -> tokbase (fp32) and xn16 (16-bit copy for proj_patch)
     WM_TRY(launch_gemm16(h, s, PS, h->p16, W16(h, e + "patch_embed.proj.weight"), W32(h, e + "patch_embed.proj.bias"),
-                         W32(h, e + "pos_embed"), T, h->tokbase, h->xn16, M, D, 768, ACT_NONE));
+                         W32(h, e + "pos_embed"), T, h->tokbase, h->xn16, M, D, 768, ACT_NONE, W16P(h, e + "patch_embed.proj.weight")));
     WM_TRY(do_tap(h, s, -3, B, h->tokbase));
     WM_TRY(launch_gemm16(h, s, PS, h->h16, W16(h, e + "hfc_embed.proj.weight"), W32(h, e + "hfc_embed.proj.bias"),
-                         nullptr, 0, nullptr, h->he16, M, HFC, 256, ACT_NONE));
+                         nullptr, 0, nullptr, h->he16, M, HFC, 256, ACT_NONE, W16P(h, e + "hfc_embed.proj.weight")));
     // ---- HFC adaptor (image_encoder.py:486-516) ----
     WM_TRY(launch_gemm16(h, s, PS, h->he16, W16(h, a + "proj_hfc.weight"), W32(h, a + "proj_hfc.bias"),
-                         W32(h, a + "pos_embed"), T, nullptr, h->hp16, M, HFC, HFC, ACT_NONE));                    // :494
+                         W32(h, a + "pos_embed"), T, nullptr, h->hp16, M, HFC, HFC, ACT_NONE, W16P(h, a + "proj_hfc.weight")));                    // :494
     WM_TRY(launch_gemm16(h, s, PS, h->xn16, W16(h, a + "proj_patch.weight"), W32(h, a + "proj_patch.bias"),
-                         nullptr, 0, h->pt32, h->pt16, M, HFC, D, ACT_NONE));                                       // :495
+                         nullptr, 0, h->pt32, h->pt16, M, HFC, D, ACT_NONE, W16P(h, a + "proj_patch.weight")));                                       // :495
     const uint16_t* wi = W16(h, a + "cross_attn.in_proj_weight");
+    const uint16_t* wip = W16P(h, a + "cross_attn.in_proj_weight");      // same element offsets: 16 rows x K are one contiguous block in both layouts
     const float* bi = W32(h, a + "cross_attn.in_proj_bias");
-    WM_TRY(launch_gemm16(h, s, PS, h->pt16, wi, bi, nullptr, 0, nullptr, h->q16, M, HFC, HFC, ACT_NONE));
-    WM_TRY(launch_gemm16(h, s, PS, h->hp16, wi + (size_t)HFC * HFC, bi + HFC, nullptr, 0, nullptr, h->kv16, M, 2 * HFC, HFC, ACT_NONE));
+    WM_TRY(launch_gemm16(h, s, PS, h->pt16, wi, bi, nullptr, 0, nullptr, h->q16, M, HFC, HFC, ACT_NONE, wip));
+    WM_TRY(launch_gemm16(h, s, PS, h->hp16, wi + (size_t)HFC * HFC, bi + HFC, nullptr, 0, nullptr, h->kv16, M, 2 * HFC, HFC, ACT_NONE,
+                         wip ? wip + (size_t)HFC * HFC : nullptr));
     WM_TRY(launch_mha16(h, s, PS, h->q16, HFC, h->kv16, 2 * HFC, h->kv16 + HFC, 2 * HFC, h->aoh16, HFC, B, HFC_HEADS,
                         HFC / HFC_HEADS, T, T));                                                                      // :500-503
     WM_TRY(launch_gemm16(h, s, PS, h->aoh16, W16(h, a + "cross_attn.out_proj.weight"), W32(h, a + "cross_attn.out_proj.bias"),
-                         h->pt32, 0, h->y1, nullptr, M, HFC, HFC, ACT_NONE));                                       // + residual :504
+                         h->pt32, 0, h->y1, nullptr, M, HFC, HFC, ACT_NONE, W16P(h, a + "cross_attn.out_proj.weight")));                                       // + residual :504
     WM_TRY(launch_layernorm(h, s, PS, h->y1, W32(h, a + "norm1.weight"), W32(h, a + "norm1.bias"), 1e-5f, h->y1n32, h->y1n16, M, HFC));
     WM_TRY(launch_gemm16(h, s, PS, h->y1n16, W16(h, a + "linear1.weight"), W32(h, a + "linear1.bias"), nullptr, 0, nullptr,
-                         h->h1_16, M, HFC, HFC, ACT_RELU));
+                         h->h1_16, M, HFC, HFC, ACT_RELU, W16P(h, a + "linear1.weight")));
     WM_TRY(launch_gemm16(h, s, PS, h->h1_16, W16(h, a + "linear2.weight"), W32(h, a + "linear2.bias"), h->y1n32, 0, h->z32,
-                         nullptr, M, HFC, HFC, ACT_NONE));                                                          // :506-508
+                         nullptr, M, HFC, HFC, ACT_NONE, W16P(h, a + "linear2.weight")));                                                          // :506-508
     WM_TRY(launch_layernorm(h, s, PS, h->z32, W32(h, a + "norm2.weight"), W32(h, a + "norm2.bias"), 1e-5f, nullptr, h->y2_16, M, HFC));
     // scramble (:512): per tile [4096 tok,1024 ch] re-read as [1024, 4096]; make it the K-contiguous A operand
     WM_TRY(launch_simple(h, s, B * 16.8e6, transpose16_kernel, dim3(T / 64, HFC / 64, B), dim3(256), (const u16*)h->y2_16, (u16*)h->y2t16, HFC, T));
     // x = proj_back(scrambled) + t   (:513-514, :131)
     WM_TRY(launch_gemm16(h, s, PS, h->y2t16, W16(h, a + "proj_back.weight"), W32(h, a + "proj_back.bias"), h->tokbase, 0,
-                         h->resid, nullptr, M, D, HFC, ACT_NONE));
+                         h->resid, nullptr, M, D, HFC, ACT_NONE, W16P(h, a + "proj_back.weight")));
     WM_TRY(do_tap(h, s, -1, B));
 
     // ---- transformer blocks (image_encoder.py:188-204) ----
@@ -1250,6 +1277,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     // bf16 for the rest and for attention.  Each producer writes its consumer's operand type directly (LayerNorm / attention /
     // GELU epilogue -> e4m3 bytes or 16-bit), so no conversion pass exists in any mix.
     bool xn_ready = false;                                  // xn16 already holds norm1 of the current residual stream
+    bool xn_packed = false;                                 // ... in LDS-image order
     for (int i = 0; i < h->depth; ++i) {
         const std::string b = e + "blocks." + std::to_string(i) + ".";
         const int PB = block_prec(h, i);
@@ -1257,15 +1285,22 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
         const int P = f8 ? WM_PREC_BF16 : PB;               // 16-bit type of this block (attention, non-fp8 GEMMs)
         const bool q8 = f8 && (h->fp8_gemms & WM_FP8_QKV), p8 = f8 && (h->fp8_gemms & WM_FP8_PROJ), m8 = f8 && (h->fp8_gemms & WM_FP8_MLP);
         auto W8 = [&](const std::string& n) { return h->w8.at(n); };
-        if (!xn_ready)
-            WM_TRY(launch_layernorm_block(h, s, q8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D));
+        // Activations that feed a 16-bit GEMM on the 256-row-tile kernel are written in LDS-image order by their producer
+        // (gemm16_v5.h "Operand layout"): norm1 -> qkv, norm2 -> lin1, lin1's GELU epilogue -> lin2.  (proj's operand, the
+        // attention output, stays row-major: a head's 80 columns do not fall on the 32-column pieces.)
+        const bool pk_qkv = !q8 && gemm16_takes_v5(M, 3 * D, D), pk_lin1 = !m8 && gemm16_takes_v5(M, 4 * D, D);
+        const bool pk_lin2 = pk_lin1 && gemm16_takes_v5(M, D, 4 * D);
+        if (!xn_ready) {
+            WM_TRY(launch_layernorm_block(h, s, q8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D, pk_qkv));
+            xn_packed = pk_qkv;
+        }
         WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, q8 ? WM_PREC_FP8 : P));
         if (q8)
             WM_TRY(launch_gemm8(h, s, P, h->xn16, W8(b + "attn.qkv.weight"), W32(h, b + "attn.qkv.weight.wscale"), W32(h, b + "attn.qkv.bias"),
                                 nullptr, nullptr, h->qkv16, nullptr, M, 3 * D, D, ACT_NONE));
         else
             WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "attn.qkv.weight"), W32(h, b + "attn.qkv.bias"), nullptr, 0, nullptr,
-                                 h->qkv16, M, 3 * D, D, ACT_NONE));
+                                 h->qkv16, M, 3 * D, D, ACT_NONE, W16P(h, b + "attn.qkv.weight"), xn_packed));
         WM_TRY(sat_check(h, s, WM_SAT_QKV, h->qkv16, (int64_t)M * 3 * D, P));
         // the attention kernels write their output as e4m3 when proj consumes e4m3
         WM_TRY(launch_encoder_attention(h, s, P, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
@@ -1278,15 +1313,18 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
                                 h->resid, h->resid, nullptr, nullptr, M, D, D, ACT_NONE));
         } else {
             int r = m8 ? 1 : launch_gemm16_ln(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, h->resid,
-                                              h->xn16, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, M, D, D);
+                                              h->xn16, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, M, D, D, W16P(h, b + "attn.proj.weight"));
             if (r < 0) return r;
             n2_ready = r == 0;
+            if (n2_ready) xn_packed = false;                 // the fused epilogue writes its LayerNorm output row-major
             if (r == 1)
                 WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
-                                     h->resid, nullptr, M, D, D, ACT_NONE));
+                                     h->resid, nullptr, M, D, D, ACT_NONE, W16P(h, b + "attn.proj.weight")));
         }
-        if (!n2_ready)
-            WM_TRY(launch_layernorm_block(h, s, m8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D));
+        if (!n2_ready) {
+            WM_TRY(launch_layernorm_block(h, s, m8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D, pk_lin1));
+            xn_packed = pk_lin1;
+        }
         WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, m8 ? WM_PREC_FP8 : P));
         xn_ready = false;
         if (m8) {
@@ -1297,19 +1335,21 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
                                 h->resid, h->resid, nullptr, nullptr, M, D, 4 * D, ACT_NONE));
         } else {
             WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.bias"), nullptr, 0, nullptr,
-                                 h->hid16, M, 4 * D, D, ACT_GELU));
+                                 h->hid16, M, 4 * D, D, ACT_GELU, W16P(h, b + "mlp.lin1.weight"), xn_packed, pk_lin2));
             WM_TRY(sat_check(h, s, WM_SAT_HID, h->hid16, (int64_t)M * 4 * D, P));
             // the fused kernel's operand type is also its LayerNorm output type: the next block's norm1 must want the same
             if (i + 1 < h->depth && block_prec(h, i + 1) == PB && !f8) {
                 const std::string nb = e + "blocks." + std::to_string(i + 1) + ".";
                 int r = launch_gemm16_ln(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, h->resid,
-                                         h->xn16, W32(h, nb + "norm1.weight"), W32(h, nb + "norm1.bias"), 1e-6f, M, D, 4 * D);
+                                         h->xn16, W32(h, nb + "norm1.weight"), W32(h, nb + "norm1.bias"), 1e-6f, M, D, 4 * D,
+                                         W16P(h, b + "mlp.lin2.weight"), pk_lin2);
                 if (r < 0) return r;
                 xn_ready = r == 0;
+                if (xn_ready) xn_packed = false;
             }
             if (!xn_ready)
                 WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
-                                     h->resid, nullptr, M, D, 4 * D, ACT_NONE));
+                                     h->resid, nullptr, M, D, 4 * D, ACT_NONE, W16P(h, b + "mlp.lin2.weight"), pk_lin2));
         }
         WM_TRY(do_tap(h, s, i, B));
     }
@@ -1317,7 +1357,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     // ---- neck (image_encoder.py:105-121,136) ----
     WM_TRY(launch_simple(h, s, B * 31.5e6, cvt_f32_to_16_kernel<FP16>, dim3(grid_for((int64_t)M * D / 4)), dim3(256), (const float*)h->resid, (u16*)h->x16last, (int64_t)M * D / 4));
     WM_TRY(sat_check(h, s, WM_SAT_LAST, h->x16last, (int64_t)M * D, PS));
-    WM_TRY(launch_gemm16(h, s, PS, h->x16last, W16(h, e + "neck.0.weight"), nullptr, nullptr, 0, h->n1, nullptr, M, OUTC, D, ACT_NONE));
+    WM_TRY(launch_gemm16(h, s, PS, h->x16last, W16(h, e + "neck.0.weight"), nullptr, nullptr, 0, h->n1, nullptr, M, OUTC, D, ACT_NONE, W16P(h, e + "neck.0.weight")));
     WM_TRY(launch_layernorm(h, s, PS, h->n1, W32(h, e + "neck.1.weight"), W32(h, e + "neck.1.bias"), 1e-6f, nullptr, h->n1n16, M, OUTC));
     WM_TRY(launch_conv3x3_16(h, s, PS, h->n1n16, W16(h, e + "neck.2.weight"), h->n2, M, OUTC, OUTC));
     WM_TRY(launch_layernorm(h, s, PS, h->n2, W32(h, e + "neck.3.weight"), W32(h, e + "neck.3.bias"), 1e-6f, h->emb_nhwc, nullptr, M, OUTC));
@@ -1368,7 +1408,7 @@ int decoder_impl(wm_handle* h, const float* keys_nhwc, float* logits, float* box
         return launch_simple(h, s, 0.0, add_bcast_kernel, dim3(grid_for((int64_t)Mk * E / 4)), dim3(256), (const float*)keys, (const float*)h->kpe, out, (int64_t)Mk, E, T);
     };
     auto ln = [&](float* x, const std::string& n, int rows) {
-        return launch_layernorm(h, s, h->prec, x, W32(h, n + ".weight"), W32(h, n + ".bias"), 1e-5f, x, nullptr, rows, E);
+        return launch_layernorm(h, s, WM_PREC_FP16, x, W32(h, n + ".weight"), W32(h, n + ".bias"), 1e-5f, x, nullptr, rows, E);   // fp32 in place: the 16-bit type is unused
     };
     // token -> image attention: q from (queries+pe), k from (keys+pe) [kin], v from keys; result added to queries
     auto token_to_image = [&](const DecAttnW& w, const float* kin) -> int {
@@ -1730,7 +1770,22 @@ extern "C" int wm_preprocess_u8_resized(const uint8_t* img_dev, float* out_dev, 
 
 extern "C" int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev, int res_mod,
                             float* out_f32_dev, void* out_16_dev, int M, int N, int K, int act, int precision, void* stream) {
-    return launch_gemm16(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, bias_dev, residual_dev, res_mod, out_f32_dev, out_16_dev, M, N, K, act);
+    const int layout = act & (WM_GEMM_W_PACKED | WM_GEMM_A_PACKED | WM_GEMM_OUT_PACKED);
+    act &= ~(WM_GEMM_W_PACKED | WM_GEMM_A_PACKED | WM_GEMM_OUT_PACKED);
+    if (layout && !gemm16_takes_v5(M, N, K))
+        return fail("wm_op_gemm16: M=%d N=%d K=%d runs on a half-width kernel, which takes row-major operands only (wm_op_gemm16_takes_packed)", M, N, K);
+    return launch_gemm16(nullptr, (hipStream_t)stream, precision, a_dev, (layout & WM_GEMM_W_PACKED) ? nullptr : w_dev, bias_dev, residual_dev, res_mod,
+                         out_f32_dev, out_16_dev, M, N, K, act, (layout & WM_GEMM_W_PACKED) ? w_dev : nullptr, (layout & WM_GEMM_A_PACKED) != 0,
+                         (layout & WM_GEMM_OUT_PACKED) != 0);
+}
+
+extern "C" int wm_op_gemm16_takes_packed(int M, int N, int K) { return gemm16_takes_v5(M, N, K) ? 1 : 0; }
+
+extern "C" int wm_op_pack16(const void* in_dev, void* out_dev, int64_t rows, int K, void* stream) {
+    if (!in_dev || !out_dev || rows <= 0 || K <= 0 || rows % 16 || K % 32) return fail("wm_op_pack16: rows=%lld K=%d (rows %% 16, K %% 32)", (long long)rows, K);
+    hipLaunchKernelGGL(pack16_lds_image_kernel, dim3(grid_for(rows * (K / 8))), dim3(256), 0, (hipStream_t)stream, (const uint4*)in_dev, (uint4*)out_dev, rows, K);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 extern "C" int wm_op_gemm16_ln(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev,
@@ -1770,8 +1825,11 @@ extern "C" int wm_op_gemm32(const float* a_dev, const float* w_dev, const float*
 
 extern "C" int wm_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, float* out_f32_dev,
                                void* out_16_dev, int64_t rows, int C, int precision, void* stream) {
+    const int packed = (precision & WM_LAYOUT_PACKED) != 0;
+    precision &= ~WM_LAYOUT_PACKED;
     if (!out_f32_dev && out_16_dev)      // the transformer blocks' form: column-tiled statistics (bit-identical to wm_op_gemm16_ln)
-        return launch_layernorm_block(nullptr, (hipStream_t)stream, precision, x_dev, gamma_dev, beta_dev, eps, out_16_dev, rows, C);
+        return launch_layernorm_block(nullptr, (hipStream_t)stream, precision, x_dev, gamma_dev, beta_dev, eps, out_16_dev, rows, C, packed);
+    if (packed) return fail("wm_op_layernorm: the LDS-image-order output exists for the 16-bit-only form");
     return launch_layernorm(nullptr, (hipStream_t)stream, precision, x_dev, gamma_dev, beta_dev, eps, out_f32_dev, out_16_dev, rows, C);
 }
 

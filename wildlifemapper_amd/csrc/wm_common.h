@@ -25,6 +25,7 @@ struct BF16 {
     using vec8 = bf16x8;
     using vec4 = bf16x4;
     static __device__ __forceinline__ elem from_f32(float x) { return (__bf16)x; }
+    static __device__ __forceinline__ elem from_f32_bounded(float x) { return (__bf16)x; }
     static __device__ __forceinline__ float to_f32(elem x) { return (float)x; }
     static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -39,10 +40,13 @@ struct FP16 {
     using vec8 = f16x8;
     using vec4 = f16x4;
     static __device__ __forceinline__ elem from_f32(float x) {
-        // saturate instead of producing inf: fp16 max is 65504
-        x = fminf(fmaxf(x, -65504.f), 65504.f);
-        return (_Float16)x;
+        // saturate instead of producing inf: fp16 max is 65504.  One v_med3_f32 (fminf(fmaxf()) costs a NaN-canonicalising
+        // v_max in front of it: 2.5 instead of 1.5 vector instructions per converted element); a NaN comes out as -65504 either way
+        return (_Float16)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
     }
+    // for values known to lie inside fp16's range (softmax probabilities <= 2^6, convex combinations of 16-bit values):
+    // no clamp, 0.5 instructions per element (v_cvt_pk_f16_f32)
+    static __device__ __forceinline__ elem from_f32_bounded(float x) { return (_Float16)x; }
     static __device__ __forceinline__ float to_f32(elem x) { return (float)x; }
     static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);

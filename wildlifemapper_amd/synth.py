@@ -216,6 +216,10 @@ def _is_norm(name: str) -> bool:
 
 def make_weight(name: str, shape, seed: int = 0, profile: str = "baseline") -> np.ndarray:
     """Fill rule per SURVEY.md §8d: non-zero pos/rel-pos tables on purpose."""
+    if profile == "outlier":
+        w = make_weight(name, shape, seed, "baseline")
+        m = _outlier_scale(name, tuple(shape))
+        return w if m is None else (w * m).astype(np.float32)
     leaf = name.rsplit(".", 1)[-1]
     if leaf in ("pos_embed", "rel_pos_h", "rel_pos_w"):
         return fill_normal(seed, name, shape, 0.02)
@@ -242,7 +246,41 @@ def make_weight(name: str, shape, seed: int = 0, profile: str = "baseline") -> n
     return w
 
 
-PROFILES = ("baseline", "sensitive")
+PROFILES = ("baseline", "sensitive", "outlier")
+
+# "outlier" profile (round 3): activation outliers of the kind trained ViTs show -- in every 8th block (from block 5) six
+# LayerNorm gamma channels x50 in norm1 and norm2, eight lin1 output rows (weight and bias) x30 and two lin2 output channels
+# x40 (two "massive" channels that then live on in the residual stream), so the 16-bit operand buffers (LayerNorm outputs,
+# packed qkv, GELU hidden, the 16-bit copy of the last block's output) carry values two orders of magnitude above the bulk.
+# The check for the fp16 default, whose range (+-65504) is what it gives up against bf16.
+OUTLIER_BLOCK_FIRST, OUTLIER_BLOCK_STEP = 5, 8
+OUTLIER_GAMMA_GAIN, OUTLIER_ROW_GAIN, OUTLIER_RESID_GAIN = 50.0, 30.0, 40.0
+
+
+def _outlier_scale(name: str, shape) -> np.ndarray | None:
+    """Per-element multiplier of the outlier profile for this tensor, or None."""
+    parts = name.split(".")
+    if len(parts) < 4 or parts[0] != "image_encoder" or parts[1] != "blocks":
+        return None
+    blk = int(parts[2])
+    if blk < OUTLIER_BLOCK_FIRST or (blk - OUTLIER_BLOCK_FIRST) % OUTLIER_BLOCK_STEP:
+        return None
+    tail = ".".join(parts[3:])
+    if tail in ("norm1.weight", "norm2.weight"):
+        m = np.ones(shape, dtype=np.float32)
+        D = shape[0]
+        m[[(17 + 211 * j + 7 * blk) % D for j in range(6)]] = OUTLIER_GAMMA_GAIN
+        return m
+    if tail in ("mlp.lin1.weight", "mlp.lin1.bias"):
+        m = np.ones(shape, dtype=np.float32)
+        R = shape[0]
+        m[[(29 + 401 * j + 13 * blk) % R for j in range(8)]] = OUTLIER_ROW_GAIN
+        return m
+    if tail in ("mlp.lin2.weight", "mlp.lin2.bias"):
+        m = np.ones(shape, dtype=np.float32)
+        m[[(101 + 577 * j) % shape[0] for j in range(2)]] = OUTLIER_RESID_GAIN      # the same two channels in every outlier block
+        return m
+    return None
 
 
 def _decoder_gain(name: str, profile: str = "baseline") -> float:
