@@ -1,0 +1,635 @@
+// Flash-style multi-head attention on MFMA 32x32x16 (bf16 / fp16), gfx950.
+//
+// Two kernels share the per-wave core below:
+//   attn_global_kernel  - 4096 (or any multiple of 64) keys per head, optional
+//                         decomposed rel-pos bias: the 4 global blocks
+//                         (image_encoder.py:246-262, 347-383) and, without the
+//                         bias, the HFC cross-attention (image_encoder.py:500-503).
+//   attn_window_kernel  - 14x14 windows with zero-padded tokens that still act
+//                         as keys/values (image_encoder.py:190-199, 265-311).
+//
+// Per wave: 32 query rows, scores computed TRANSPOSED (S^T = K Q^T) so that a
+// lane owns one query column: its 32x32 accumulator registers are that query's
+// scores for 16 of the tile's 32 keys, the partner lane (lane^32) holds the other
+// 16.  Softmax is therefore lane-local plus one cross-half exchange, and the
+// exponentiated tile is already the B operand of the P*V product
+// (O^T = V^T P^T, cdna_hip_programming.md §3 "An accumulator tile as the next
+// MFMA's operand"), whose A operand V^T comes from the row-major V tile in LDS
+// through ds_read_b64_tr_b16 (T10).
+//
+// The rel-pos bias is never materialised per (query,key) pair in memory:
+//   bias[q,(kh,kw)] = q.Rh[qh-kh+S-1] + q.Rw[qw-kw+S-1]   (unscaled q, :376-381)
+// For global attention a key tile is one grid row (kh fixed, kw = 0..63), so the
+// kw-term is the same 64-vector for every tile (kept in registers, used as the
+// MFMA accumulator's initial value) and the kh-term is one scalar per tile.
+// Both are produced in the prologue by MFMA products Q x table^T.
+#pragma once
+#include "wm_common.h"
+
+namespace wm {
+
+struct AttnArgs {
+    const u16* q; const u16* k; const u16* v;   // 16-bit, row = token
+    u16* out;
+    int q_stride, k_stride, v_stride, out_stride;   // elements between consecutive tokens
+    int nq, nk;                                     // tokens per image (queries / keys)
+    float scale;                                    // head_dim^-0.5
+    const float* rel_h; const float* rel_w;         // [2*S-1, HD] fp32 or null
+    const float* qkv_bias;                          // window kernel: [3*D] fp32 (padded tokens)
+    int heads;
+    unsigned char* out8;                            // WM_PREC_FP8: write the output as e4m3 bytes (row stride out_stride bytes) instead of 16-bit
+};
+
+template <int HD> struct AttnGeom {
+    static constexpr int KS = HD * 2 + 16;                      // K row stride (bytes): odd multiple of 16 B
+    static constexpr int VS = (HD == 128) ? 320 : 192;          // V row stride (bytes): odd multiple of 64 B
+    static constexpr int NKS = HD / 16;                         // QK^T k-steps
+    static constexpr int NDT = (HD + 31) / 32;                  // 32-row O^T tiles
+    static constexpr int CH = HD / 8;                           // 16-byte chunks per row
+    // HD = 80: the last 32-row O^T tile has 16 spare rows.  The V image's pad column HD is set to 1.0 once, so row HD
+    // of O^T = sum_k P[k][q] = the softmax denominator, from the matrix pipe instead of 32 v_add per tile (and it is
+    // the sum of exactly the rounded P values the numerator uses).  Lane (c, h = 0) holds it in o[NDT-1][LSUM_R].
+    static constexpr bool LSUM_IN_O = (HD % 32) != 0;
+    static constexpr int LSUM_R = ((HD % 32) / 8) * 4;
+    static_assert(!LSUM_IN_O || (HD % 8) == 0, "pad column must fall on accumulator register LSUM_R of half 0");
+};
+
+template <class T>
+__device__ __forceinline__ typename T::vec8 lds_read_v8(const char* p) {
+    return *(const typename T::vec8*)p;
+}
+
+// V^T fragment for one 32x32x16 k-step: two transposed reads of 4 keys x 16 dims.
+template <class T>
+__device__ __forceinline__ typename T::vec8 lds_read_vT(const char* p_first, int second_off) {
+    typedef __attribute__((address_space(3))) s16x4* lptr;
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p_first));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p_first + second_off));
+    s16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return __builtin_bit_cast(typename T::vec8, r);
+}
+
+// Online-softmax state of one wave (32 queries, lane = query column + 32*half).
+template <int NDT> struct SoftmaxState {
+    float m;          // running max (log2 domain)
+    float l;          // running sum, this lane's half of the keys only
+    f32x16 o[NDT];    // O^T accumulators
+    __device__ __forceinline__ void init() {
+        m = -1e30f; l = 0.f;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
+    }
+};
+
+// One key tile of NT*32 keys.  s[t] hold the raw accumulators; the log2-domain score of an element is
+// c1 * (s + tile_bias) (c1 = softmax scale * log2 e; tile_bias = a per-query constant of this tile, e.g. the
+// rel-pos kh-term divided by the scale).  kvalid: number of valid keys in the tile (keys >= kvalid are masked).
+// sV: LDS address of the tile's V rows.
+// VALU budget per score (this loop is VALU-bound next to 22 MFMAs per tile): max, one FMA folding scale, bias and
+// running max into the exp2 argument, exp2, sum, convert.  The O accumulators are rescaled only when the running
+// max grew by more than RESCALE_THR (log2 units), so most tiles skip the O-wide multiply; until then P values are
+// bounded by 2^RESCALE_THR instead of 1, harmless in fp32 accumulators and for 16-bit floating P.
+constexpr float RESCALE_THR = 6.0f;
+
+template <class T, int HD, int NT>
+__device__ __forceinline__ void softmax_pv(SoftmaxState<AttnGeom<HD>::NDT>& st, f32x16 (&s)[NT],
+                                           float c1, float tile_bias, int kvalid, const char* sV, int lane) {
+    using G = AttnGeom<HD>;
+    const int h = lane >> 5;
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (key >= kvalid) s[t][r] = -1e30f;          // folds away when the tile is full
+            mx = fmaxf(mx, s[t][r]);
+        }
+    mx = (mx + tile_bias) * c1;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // defer-max: keep the old reference point unless some query's max grew by more than the threshold
+    float m_use = st.m;
+    if (!__all(mx - st.m <= RESCALE_THR)) {
+        const float m_new = fmaxf(st.m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(st.m - m_new);
+        st.l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < G::NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
+        st.m = m_new;
+        m_use = m_new;
+    }
+    const float off = tile_bias * c1 - m_use;
+    float ls = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][r], c1, off));
+            s[t][r] = pv;
+            if constexpr (!G::LSUM_IN_O) ls += pv;      // else: row HD of O^T accumulates the sum (V pad column = 1)
+        }
+    st.l += ls;
+
+    // P^T fragments -> O^T += V^T P^T.  k-step ks covers keys 16*ks .. 16*ks+15 of the tile.
+    const int g = lane >> 4;
+    // transposed-read address: group g = 16-lane group; half h = g>>1 picks keys +4h, (g&1) picks dims +16
+    const int lq = (lane & 15) >> 2, lp = lane & 3;
+    const int v_lane_off = (4 * (g >> 1) + lq) * G::VS + (16 * (g & 1) + 4 * lp) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2 * NT; ++ks) {
+        typename T::vec8 pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] = T::from_f32_bounded(s[ks >> 1][8 * (ks & 1) + j]);     // P <= 2^RESCALE_THR
+#pragma unroll
+        for (int dt = 0; dt < G::NDT; ++dt) {
+            const char* p = sV + (16 * ks) * G::VS + dt * 64 + v_lane_off;
+            typename T::vec8 va = lds_read_vT<T>(p, 8 * G::VS);
+            st.o[dt] = T::mfma32(va, pb, st.o[dt]);
+        }
+    }
+}
+
+// S^T[t] += K[tile rows 32t..32t+31] * Q^T over HD, K rows in LDS with stride KS.
+template <class T, int HD, int NT>
+__device__ __forceinline__ void qk_tile(f32x16 (&s)[NT], const typename T::vec8 (&qf)[AttnGeom<HD>::NKS],
+                                        const char* sK, int lane) {
+    using G = AttnGeom<HD>;
+    const int r31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            typename T::vec8 kf = lds_read_v8<T>(sK + (32 * t + r31) * G::KS + (16 * ks + 8 * h) * 2);
+            s[t] = T::mfma32(kf, qf[ks], s[t]);
+        }
+}
+
+// Set the pad column HD of `rows` V rows (stride VS) to 1.0 (see AttnGeom::LSUM_IN_O).
+template <class T, int HD>
+__device__ __forceinline__ void v_pad_ones(char* sV, int rows, int tid, int nthreads) {
+    using G = AttnGeom<HD>;
+    if constexpr (G::LSUM_IN_O) {
+        const typename T::elem one = T::from_f32(1.0f);
+        for (int r = tid; r < rows; r += nthreads) *(typename T::elem*)(sV + r * G::VS + HD * 2) = one;
+    }
+}
+
+// Normalise and store O^T: lane (c = lane&31, h) holds dims 32dt + (r&3) + 8(r>>2) + 4h of query c.
+template <class T, int HD>
+__device__ __forceinline__ void store_out(SoftmaxState<AttnGeom<HD>::NDT>& st, u16* out_row, int lane, bool valid, unsigned char* out8_row = nullptr) {
+    using G = AttnGeom<HD>;
+    const int h = lane >> 5;
+    float l;
+    if constexpr (G::LSUM_IN_O) l = __shfl(st.o[G::NDT - 1][G::LSUM_R], lane & 31, 64);
+    else l = st.l + __shfl_xor(st.l, 32, 64);
+    const float inv = 1.0f / l;
+    if (!valid) return;
+#pragma unroll
+    for (int dt = 0; dt < G::NDT; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int d = 32 * dt + 8 * rg + 4 * h;
+            if (d < HD) {
+                if (out8_row) {                              // wave-uniform: e4m3 A operand of the fp8 proj GEMM (gemm8.h)
+                    const f32x4 v{st.o[dt][4 * rg] * inv, st.o[dt][4 * rg + 1] * inv, st.o[dt][4 * rg + 2] * inv, st.o[dt][4 * rg + 3] * inv};
+                    *(unsigned*)(out8_row + d) = pack4_e4m3(v);
+                } else {
+                    typename T::vec4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = T::from_f32_bounded(st.o[dt][4 * rg + j] * inv);     // a convex combination of V rows
+                    *(typename T::vec4*)(out_row + d) = o;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
+// Global attention (key tile = 64 keys = one grid row when REL)
+// grid (nq/128, heads, batch), 256 threads.
+// ---------------------------------------------------------------------------
+template <int HD, bool REL> struct GlobalLds {
+    using G = AttnGeom<HD>;
+    static constexpr int WAVE_F = 32 * 65;                                    // floats per wave (padded staging)
+    static constexpr int RELH_BYTES = REL ? 4 * WAVE_F * 4 : 0;              // [wave][kh][query] fp32, aliased with [query][65] staging
+    static constexpr int K_BYTES = 64 * G::KS, V_BYTES = 64 * G::VS;
+    static constexpr int KV_OFF = RELH_BYTES;
+    static constexpr int TOTAL = RELH_BYTES + 2 * (K_BYTES + V_BYTES);
+};
+
+template <class T, int HD, bool REL>
+__global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
+    using G = AttnGeom<HD>;
+    using L = GlobalLds<HD, REL>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float c1 = p.scale * 1.44269504088896340736f;
+
+    const u16* qb = p.q + ((size_t)b * p.nq) * p.q_stride + head * HD;
+    const u16* kb = p.k + ((size_t)b * p.nk) * p.k_stride + head * HD;
+    const u16* vb = p.v + ((size_t)b * p.nk) * p.v_stride + head * HD;
+
+    // Q fragments (B operand): lane holds Q[q0+c][16ks + 8h .. +7]
+    typename T::vec8 qf[G::NKS];
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks)
+        qf[ks] = *(const typename T::vec8*)(qb + (size_t)(q0 + c) * p.q_stride + 16 * ks + 8 * h);
+
+    char* sKV = smem + L::KV_OFF;
+    f32x16 relw[2];
+    float* sRelH = (float*)smem + wave * (32 * 65);
+
+    if constexpr (REL) {
+        // ---- prologue: rel_w (registers) and rel_h (LDS) for this wave's 32 queries ----
+        // table image: 128 rows x HD 16-bit, row stride KS, rows >= 127 zero
+        const int qh = q0 >> 6, qw0 = q0 & 63;
+        const float inv_scale = 1.0f / p.scale;
+        char* sTab = sKV;
+        float* sT = (float*)smem + wave * (32 * 65);          // [query c][65] fp32 staging (padded: conflict-free)
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {
+            const float* tab = which == 0 ? p.rel_w : p.rel_h;
+            __syncthreads();
+            for (int e = tid; e < 128 * (HD / 4); e += 256) {
+                const int row = e / (HD / 4), c4 = e % (HD / 4);
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < 127) v = *(const f32x4*)(tab + (size_t)row * HD + c4 * 4);
+                typename T::vec4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+                *(typename T::vec4*)(sTab + row * G::KS + c4 * 8) = o;
+            }
+            __syncthreads();
+            if (which == 0) {
+                // T_w^T[i][c] = Rw[i].q_c for i in two passes of 64; pick i = qw + 63 - kw
+                const int qw = qw0 + c;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) relw[t][r] = 0.f;
+#pragma unroll 1
+                for (int pass = 0; pass < 2; ++pass) {
+                    f32x16 acc[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                    qk_tile<T, HD, 2>(acc, qf, sTab + pass * 64 * G::KS, lane);
+                    // stage as [c][i_local]
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int il = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            sT[c * 65 + il] = acc[t][r];
+                        }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): same-wave LDS RAW
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int kw = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            const int idx = qw + 63 - kw;
+                            if ((idx >> 6) == pass) relw[t][r] = sT[c * 65 + (idx & 63)] * inv_scale;
+                        }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                }
+            } else {
+                // T_h^T[kh][c] = Rh[qh + 63 - kh].q_c : A rows taken in reversed order
+                f32x16 acc[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                const int r31 = lane & 31;
+#pragma unroll
+                for (int ks = 0; ks < G::NKS; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int row = qh + 63 - (32 * t + r31);
+                        typename T::vec8 kf = lds_read_v8<T>(sTab + row * G::KS + (16 * ks + 8 * h) * 2);
+                        acc[t] = T::mfma32(kf, qf[ks], acc[t]);
+                    }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kh = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        sRelH[kh * 32 + c] = acc[t][r] * inv_scale;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- main loop over key tiles of 64 ----
+    const int ntiles = p.nk / 64;
+    constexpr int NCH = 64 * G::CH;                 // 16-B chunks per K (or V) tile
+    constexpr int PER = (NCH + 255) / 256;
+    s16x8 kreg[PER], vreg[PER];
+
+    // per-thread source pointers of the staging chunks, advanced by one tile per issue (no per-tile address math)
+    const u16* kp[PER];
+    const u16* vp[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = min(tid + i * 256, NCH - 1);
+        kp[i] = kb + (size_t)(e / G::CH) * p.k_stride + (e % G::CH) * 8;
+        vp[i] = vb + (size_t)(e / G::CH) * p.v_stride + (e % G::CH) * 8;
+    }
+    const size_t k_step = (size_t)64 * p.k_stride, v_step = (size_t)64 * p.v_stride;
+    auto issue = [&](int) {                          // tiles are requested in order
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (tid + i * 256 < NCH) {
+                kreg[i] = *(const s16x8*)kp[i];
+                vreg[i] = *(const s16x8*)vp[i];
+            }
+            kp[i] += k_step;
+            vp[i] += v_step;
+        }
+    };
+    v_pad_ones<T, HD>(sKV + L::K_BYTES, 64, tid, 256);
+    v_pad_ones<T, HD>(sKV + (L::K_BYTES + L::V_BYTES) + L::K_BYTES, 64, tid, 256);
+    auto commit = [&](int buf) {
+        char* sK = sKV + buf * (L::K_BYTES + L::V_BYTES);
+        char* sV = sK + L::K_BYTES;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * 256;
+            if (e < NCH) {
+                const int key = e / G::CH, ch = e % G::CH;
+                *(s16x8*)(sK + key * G::KS + ch * 16) = kreg[i];
+                *(s16x8*)(sV + key * G::VS + ch * 16) = vreg[i];
+            }
+        }
+    };
+
+    SoftmaxState<G::NDT> st;
+    st.init();
+    issue(0);
+    commit(0);
+    __syncthreads();
+
+    for (int j = 0; j < ntiles; ++j) {
+        const int buf = j & 1;
+        if (j + 1 < ntiles) issue(j + 1);
+        const char* sK = sKV + buf * (L::K_BYTES + L::V_BYTES);
+        const char* sV = sK + L::K_BYTES;
+        f32x16 s[2];
+        float rh = 0.f;
+        if constexpr (REL) {
+            rh = sRelH[j * 32 + c];                       // kh-term: one scalar per query and tile, applied inside the exp2 FMA
+#pragma unroll
+            for (int t = 0; t < 2; ++t) s[t] = relw[t];    // kw-term: the accumulators' initial value
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+        }
+        qk_tile<T, HD, 2>(s, qf, sK, lane);
+        softmax_pv<T, HD, 2>(st, s, c1, rh, 64, sV, lane);
+        if (j + 1 < ntiles) commit(buf ^ 1);
+        __syncthreads();
+    }
+    u16* orow = p.out + ((size_t)b * p.nq + q0 + c) * p.out_stride + head * HD;
+    unsigned char* orow8 = p.out8 ? p.out8 + ((size_t)b * p.nq + q0 + c) * p.out_stride + head * HD : nullptr;
+    store_out<T, HD>(st, orow, lane, true, orow8);
+}
+
+// ---------------------------------------------------------------------------
+// Window attention: one workgroup per (tile, window, head); all 196 keys of the
+// window (incl. padded tokens, whose k/v are the qkv bias) resident in LDS.
+// grid (25, heads, batch), 448 threads = 7 waves, wave w owns query slots 32w..32w+31.
+//
+// Rel-pos bias per wave: T[c][i] = q_c . table[i] by one MFMA pass over the 64-row
+// table image (rel_h rows 0..26, rel_w rows 32..58), staged per wave in LDS; each
+// lane then gathers its query's 14 + 14 values U[kh] = T[qh-kh+13], V[kw] = T[32+qw-kw+13]
+// into registers.  Key slots are laid out 14 x 16 (two zero pad columns), so that in the
+// fully unrolled key loop a score's bias is one add of two registers (see the key loop).
+// ---------------------------------------------------------------------------
+template <int HD> struct WindowLds {
+    using G = AttnGeom<HD>;
+    static constexpr int NKEY = 224;                                       // 196 padded to 7 x 32
+    static constexpr int NWAVE = 7;
+    static constexpr int K_BYTES = NKEY * G::KS, V_BYTES = NKEY * G::VS;
+    static constexpr int TAB_BYTES = 64 * G::KS;                           // rel_h rows 0..26, rel_w rows 32..58
+    static constexpr int T_BYTES = NWAVE * 32 * 65 * 4;                    // per wave [query][65] fp32
+    static constexpr int K_OFF = 0, V_OFF = K_BYTES, TAB_OFF = V_OFF + V_BYTES, T_OFF = TAB_OFF + TAB_BYTES;
+    static constexpr int TOTAL = T_OFF + T_BYTES;
+};
+
+template <class T, int HD>
+__global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nitems) {
+    using G = AttnGeom<HD>;
+    using L = WindowLds<HD>;
+    constexpr int WS = 14, GRID = 64, NWIN = 5, NTOK = WS * WS, NTHR = 448;
+    constexpr int NPF = (L::NKEY * G::CH) / NTHR;                // 16-byte K (and V) chunks per thread per item
+    static_assert((L::NKEY * G::CH) % NTHR == 0, "staging split");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int D = p.heads * HD;
+    const float c1 = p.scale * 1.44269504088896340736f;
+    const float inv_scale = 1.0f / p.scale;
+
+    char* sK = smem + L::K_OFF;
+    char* sV = smem + L::V_OFF;
+    char* sTab = smem + L::TAB_OFF;
+    float* sT = (float*)(smem + L::T_OFF) + wave * (32 * 65);
+
+    // Persistent: one workgroup per CU walks items (tile, window, head).  All 196 keys of a window live in
+    // LDS (one workgroup per CU), so nothing else on the CU could hide the latency of staging them: the next
+    // item's K / V chunks and Q fragments are fetched into registers while the current item computes.
+    // Item order: heads of one window are neighbours and, through the XCD remap, share an L2.
+    auto decode = [&](int item, int& b, int& win, int& head) {
+        head = item % p.heads;
+        win = (item / p.heads) % (NWIN * NWIN);
+        b = item / (p.heads * NWIN * NWIN);
+    };
+
+    s16x8 kreg[NPF], vreg[NPF];
+    auto prefetch_kv = [&](int item) {
+        int b, win, head;
+        decode(item, b, win, head);
+        const int wy = win / NWIN, wx = win % NWIN;
+        const u16* base = p.q + ((size_t)b * GRID * GRID) * p.q_stride + head * HD;   // packed qkv: q +0, k +D, v +2D
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + i * NTHR;
+            const int key = e / G::CH, ch = e % G::CH;                                  // key slot = 16 kh + kw (kw 14, 15: zero rows)
+            s16x8 kv8 = s16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv8 = kv8;
+            if ((key & 15) < WS) {
+                const int y = wy * WS + (key >> 4), x = wx * WS + (key & 15);
+                if (y < GRID && x < GRID) {
+                    const u16* row = base + (size_t)(y * GRID + x) * p.q_stride;
+                    kv8 = *(const s16x8*)(row + D + ch * 8);
+                    vv8 = *(const s16x8*)(row + 2 * D + ch * 8);
+                } else {
+                    // zero-padded token after norm1 -> qkv = bias (image_encoder.py:190-194, 281)
+                    typename T::vec8 tk, tv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        tk[j] = T::from_f32(p.qkv_bias[D + head * HD + ch * 8 + j]);
+                        tv[j] = T::from_f32(p.qkv_bias[2 * D + head * HD + ch * 8 + j]);
+                    }
+                    kv8 = __builtin_bit_cast(s16x8, tk);
+                    vv8 = __builtin_bit_cast(s16x8, tv);
+                }
+            }
+            kreg[i] = kv8;
+            vreg[i] = vv8;
+        }
+    };
+    auto commit_kv = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + i * NTHR;
+            const int key = e / G::CH, ch = e % G::CH;
+            *(s16x8*)(sK + key * G::KS + ch * 16) = kreg[i];
+            *(s16x8*)(sV + key * G::VS + ch * 16) = vreg[i];
+        }
+    };
+    // This wave's 32 query slots of an item.  Queries are the window's REAL tokens only, packed densely (round 3): an edge
+    // window (wy or wx = 4) holds 8 instead of 14 rows / columns of the 64 x 64 grid, i.e. 112 (corner: 64) tokens instead of
+    // 196, so its queries fill 4 (2) waves instead of 7 and the other waves skip the item's compute: on those 9 of 25 windows
+    // every SIMD then runs one wave instead of two.  (Keys keep the 14 x 16 slot layout: padded tokens DO act as keys.)
+    const int qi = wave * 32 + c;                         // query slot (0..223)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);               // wave-uniform copy (SGPR): the skip test below is scalar
+    struct QInfo { bool valid; size_t row; int qh, qw; bool wave_active; };
+    auto q_info = [&](int item) {
+        int b, win, head;
+        decode(item, b, win, head);
+        const int wy = win / NWIN, wx = win % NWIN;
+        const int vh = wy == NWIN - 1 ? GRID - (NWIN - 1) * WS : WS, vw = wx == NWIN - 1 ? GRID - (NWIN - 1) * WS : WS;
+        const bool valid = qi < vh * vw;
+        const int qh = valid ? (vw == WS ? qi / WS : qi / (GRID - (NWIN - 1) * WS)) : 0;
+        const int qw = valid ? qi - qh * vw : 0;
+        const size_t tok = (size_t)((wy * WS + qh) * GRID + wx * WS + qw);      // slot 0's token for the idle lanes: a valid address
+        return QInfo{valid, (size_t)b * GRID * GRID + tok, qh, qw, wave_u * 32 < vh * vw};
+    };
+    auto load_q = [&](typename T::vec8 (&qf)[G::NKS], int item) {
+        int b, win, head;
+        decode(item, b, win, head);
+        const QInfo qi_ = q_info(item);
+        const u16* src = p.q + qi_.row * p.q_stride + head * HD;
+#pragma unroll
+        for (int ks = 0; ks < G::NKS; ++ks) qf[ks] = *(const typename T::vec8*)(src + 16 * ks + 8 * h);
+    };
+
+    // rel-pos tables: the same for every item of this launch
+    for (int e = tid; e < 64 * (HD / 4); e += NTHR) {
+        const int row = e / (HD / 4), c4 = e % (HD / 4);
+        const int tr = row & 31;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tr < 2 * WS - 1) v = *(const f32x4*)((row < 32 ? p.rel_h : p.rel_w) + (size_t)tr * HD + c4 * 4);
+        typename T::vec4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+        *(typename T::vec4*)(sTab + row * G::KS + c4 * 8) = o;
+    }
+
+    const int Gd = gridDim.x;
+    int item = xcd_remap(blockIdx.x, Gd);
+    if (item >= nitems) return;
+    typename T::vec8 qf[G::NKS], qn[G::NKS];
+    prefetch_kv(item);
+    load_q(qf, item);
+    commit_kv();
+    v_pad_ones<T, HD>(sV, L::NKEY, tid, NTHR);            // the staging never touches the pad columns again
+    __syncthreads();
+
+    while (true) {
+        const int next = item + Gd;
+        const bool has_next = next < nitems;
+        if (has_next) {                                   // in flight during this item's compute
+            prefetch_kv(next);
+            load_q(qn, next);
+        }
+        // (q_info is evaluated twice per item, here and at the store, so that none of it stays live across the key loop:
+        // the kernel sits at the 256-register limit)
+        const bool wave_active = q_info(item).wave_active;
+        if (wave_active) {                                // wave-uniform: waves without a real query skip the item's compute
+        const int qh = q_info(item).qh, qw = q_info(item).qw;
+        // T[c][i]: i<32 -> q.rel_h[i], i>=32 -> q.rel_w[i-32], pre-divided by the softmax scale
+        float U[WS], V[WS];
+        {
+            f32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            qk_tile<T, HD, 2>(acc, qf, sTab, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int il = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    sT[c * 65 + il] = acc[t][r] * inv_scale;
+                }
+            // table rows 27..31 are zero, so out-of-window slots (qh, qw up to 15) read zeros
+#pragma unroll
+            for (int k = 0; k < WS; ++k) {
+                U[k] = sT[c * 65 + (qh - k + WS - 1)];
+                V[k] = sT[c * 65 + 32 + (qw - k + WS - 1)];
+            }
+        }
+        SoftmaxState<G::NDT> st;
+        st.init();
+        // Key slots are laid out 14 rows (kh) x 16 columns (kw; 14 and 15 are zero rows, masked through the bias): a 32-key MFMA
+        // tile is 2 kh rows, so for accumulator register r of lane half h the key is kh = 2 (tile) + (r >> 3),
+        // kw = (r & 3) + 8 ((r >> 2) & 1) + 4 h: kh is a compile-time constant and kw depends on the lane only through h.
+        // Each lane therefore pre-selects its 8 kw values once (Vsel, -1e30 for the two pad columns) and a score's rel-pos
+        // bias is ONE add of two registers, U[kh] + Vsel[idx]; the 224 slots are 3 steps of 64 keys + 1 of 32.
+        float Vsel[8];
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8) {
+            const int kw0 = (i8 & 3) + 8 * (i8 >> 2);                              // half 0; half 1: + 4
+            Vsel[i8] = h ? (kw0 + 4 < WS ? V[kw0 + 4 < WS ? kw0 + 4 : 0] : -1e30f) : V[kw0 < WS ? kw0 : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            f32x16 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][r] = U[4 * j + 2 * t + (r >> 3)] + Vsel[(r & 3) + 4 * ((r >> 2) & 1)];
+            qk_tile<T, HD, 2>(s, qf, sK + j * 64 * G::KS, lane);
+            softmax_pv<T, HD, 2>(st, s, c1, 0.f, 64, sV + j * 64 * G::VS, lane);
+        }
+        {
+            f32x16 s[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[0][r] = U[12 + (r >> 3)] + Vsel[(r & 3) + 4 * ((r >> 2) & 1)];
+            qk_tile<T, HD, 1>(s, qf, sK + 192 * G::KS, lane);
+            softmax_pv<T, HD, 1>(st, s, c1, 0.f, 32, sV + 192 * G::VS, lane);
+        }
+        {
+            int b, win, head;
+            decode(item, b, win, head);
+            const QInfo qo = q_info(item);
+            u16* orow = p.out + qo.row * p.out_stride + head * HD;
+            unsigned char* orow8 = p.out8 ? p.out8 + qo.row * p.out_stride + head * HD : nullptr;
+            store_out<T, HD>(st, orow, lane, qo.valid, orow8);
+        }
+        }                                                 // wave_active
+        if (!has_next) break;
+        __syncthreads();                                  // every wave is done with this item's K / V
+        commit_kv();
+#pragma unroll
+        for (int ks = 0; ks < G::NKS; ++ks) qf[ks] = qn[ks];
+        item = next;
+        __syncthreads();
+    }
+}
+
+}  // namespace wm

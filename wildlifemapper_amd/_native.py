@@ -9,7 +9,8 @@ from typing import Optional
 import torch  # noqa: F401  (must be imported first so both share one HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwm_hip.so")
+# WM_HIP_LIB: another build of the same library (A/B runs of two builds in one gpurun call); still no fallback of any kind
+LIB_PATH = os.environ.get("WM_HIP_LIB") or os.path.join(_HERE, "libwm_hip.so")
 
 PREC_BF16, PREC_FP16, PREC_FP8 = 0, 1, 2
 PREC_BY_NAME = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "fp8": PREC_FP8}

@@ -126,6 +126,38 @@ __global__ __launch_bounds__(256) void layernorm_tiled_kernel(const float* __res
     }
     float rstd;
     const float mean = ln_combine(mk, qk, ntile, (float)BN, (float)C, eps, rstd);
+    if constexpr (!std::is_same<T, FP8>::value) {
+        if (packed) {
+            // The output is the A operand of a gemm16_v5 launch: LDS-image order (gemm16_v5.h "Operand layout").  A row's 64 bytes
+            // of one K-step are contiguous there and the workgroup's 4 consecutive rows make 256 B, so the rows go through LDS and
+            // the workgroup stores 16 bytes per thread, 256-byte runs (a wave storing its own row would write 64-byte pieces 1 KiB
+            // apart: measured +15 % on this HBM-bound kernel).  rows % 16 == 0: every workgroup is full.
+            __shared__ __attribute__((aligned(16))) u16 stage[4][1280];
+            const int w = threadIdx.x >> 6;
+            if (live) {
+#pragma unroll
+                for (int kk = 0; kk < CPT; ++kk) {
+                    const int c0 = k * BN + (l16 + 16 * kk) * 4;
+                    const f32x4 g = *(const f32x4*)(gamma + c0);
+                    const f32x4 b = *(const f32x4*)(beta + c0);
+                    typename T::vec4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = T::from_f32(ln_apply(v[kk][j], mean, rstd, g[j], b[j]));
+                    *(typename T::vec4*)(&stage[w][c0]) = o;
+                }
+            }
+            __syncthreads();
+            const int64_t row0 = (int64_t)blockIdx.x * 4;
+            const int r0 = (int)(row0 & 15);                               // 0, 4, 8 or 12: the 4 rows share r >> 2, i.e. one swizzle key
+            const int key = (0 - (r0 >> 2)) & 3;
+            uint4* dst = (uint4*)(out16 + (row0 >> 4) * (int64_t)(C >> 5) * 512) + r0 * 4;      // + kt * 64 + (row in 4) * 4 + position chunk
+            for (int i = threadIdx.x; i < (C >> 5) * 16; i += 256) {       // per K-step: 4 rows x 4 chunks = 256 contiguous bytes
+                const int kt = i >> 4, rr = (i >> 2) & 3, pc = i & 3;
+                dst[kt * 64 + rr * 4 + pc] = *(const uint4*)(&stage[rr][kt * 32 + ((pc ^ key) << 3)]);
+            }
+            return;
+        }
+    }
     if (!live) return;
 #pragma unroll
     for (int kk = 0; kk < CPT; ++kk) {
@@ -135,8 +167,7 @@ __global__ __launch_bounds__(256) void layernorm_tiled_kernel(const float* __res
         f32x4 y;
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = ln_apply(v[kk][j], mean, rstd, g[j], b[j]);
-        // packed: the output is the A operand of a gemm16_v5 launch and is written in LDS-image order (16-bit types only)
-        store4_as<T>(out16, packed ? lds_image_index(row, c0, C) : row * C + c0, y);
+        store4_as<T>(out16, row * C + c0, y);
     }
 }
 

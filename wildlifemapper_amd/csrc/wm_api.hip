@@ -231,6 +231,7 @@ struct wm_handle {
     std::map<std::string, float*> w32;
     std::vector<void*> allocs;
     Profiler prof;
+    bool row_major = false;                 // WM_ROW_MAJOR_OPERANDS=1 (A/B runs): no operand in LDS-image order
     bool sat_on = false;                    // wm_debug_saturation_enable
     unsigned long long* sat_counts = nullptr;   // [WM_SAT_COUNT] device counters
     int tap_which = -2;
@@ -995,6 +996,7 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     h->fp16_tail = getenv("WM_FP16_TAIL") ? atoi(getenv("WM_FP16_TAIL")) : 0;
     h->fp8_bf16_tail = getenv("WM_FP8_BF16_TAIL") ? atoi(getenv("WM_FP8_BF16_TAIL")) : 0;
     h->fp8_bf16_head = getenv("WM_FP8_BF16_HEAD") ? atoi(getenv("WM_FP8_BF16_HEAD")) : 0;
+    h->row_major = getenv("WM_ROW_MAJOR_OPERANDS") && atoi(getenv("WM_ROW_MAJOR_OPERANDS")) != 0;
     h->fp8_gemms = cfg->fp8_gemms ? (cfg->fp8_gemms & WM_FP8_ALL) : (getenv("WM_FP8_GEMMS") ? (atoi(getenv("WM_FP8_GEMMS")) & WM_FP8_ALL) : WM_FP8_ALL);
     if (cfg->precision == WM_PREC_FP8 && h->fp8_gemms == 0) { delete h; return fail("wm_create: fp8_gemms selects no GEMM"); }
     h->D = cfg->embed_dim; h->depth = cfg->depth; h->heads = cfg->num_heads; h->hd = hd;
@@ -1192,7 +1194,11 @@ int check_ready(wm_handle* h, int batch, const char* fn, bool need_enc, bool nee
 }
 
 const uint16_t* W16(wm_handle* h, const std::string& n) { return h->w16.at(n); }
-const uint16_t* W16P(wm_handle* h, const std::string& n) { auto it = h->w16p.find(n); return it == h->w16p.end() ? nullptr : it->second; }
+const uint16_t* W16P(wm_handle* h, const std::string& n) {
+    if (h->row_major) return nullptr;
+    auto it = h->w16p.find(n);
+    return it == h->w16p.end() ? nullptr : it->second;
+}
 const float* W32(wm_handle* h, const std::string& n) { return h->w32.at(n); }
 
 int do_tap(wm_handle* h, hipStream_t s, int which, int batch, const float* src = nullptr) {
@@ -1288,7 +1294,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
         // Activations that feed a 16-bit GEMM on the 256-row-tile kernel are written in LDS-image order by their producer
         // (gemm16_v5.h "Operand layout"): norm1 -> qkv, norm2 -> lin1, lin1's GELU epilogue -> lin2.  (proj's operand, the
         // attention output, stays row-major: a head's 80 columns do not fall on the 32-column pieces.)
-        const bool pk_qkv = !q8 && gemm16_takes_v5(M, 3 * D, D), pk_lin1 = !m8 && gemm16_takes_v5(M, 4 * D, D);
+        const bool pk_qkv = !h->row_major && !q8 && gemm16_takes_v5(M, 3 * D, D), pk_lin1 = !h->row_major && !m8 && gemm16_takes_v5(M, 4 * D, D);
         const bool pk_lin2 = pk_lin1 && gemm16_takes_v5(M, D, 4 * D);
         if (!xn_ready) {
             WM_TRY(launch_layernorm_block(h, s, q8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D, pk_qkv));
