@@ -375,7 +375,8 @@ def main() -> None:
             traffic = None
             traffic_src = None
             try:   # HBM bytes per GEMM launch from the PMC passes committed under profiles/ (collected offline with rocprofv3)
-                for name in (("r2_pmc_traffic.json" if a.precision == "bf16" else f"r2_{a.precision}_pmc_traffic.json"), "r1g_pmc_traffic.json"):   # bf16 keeps its round-2 file name
+                for name in (f"r3_{a.precision}_pmc_traffic.json", ("r2_pmc_traffic.json" if a.precision == "bf16" else f"r2_{a.precision}_pmc_traffic.json"),
+                             "r1g_pmc_traffic.json"):   # newest round first; bf16 keeps its round-2 file name
                     with open(os.path.join(ROOT, "profiles", name)) as f:
                         t = json.load(f)
                     # the committed counters belong to one workload: use them only for that one

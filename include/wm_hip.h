@@ -76,6 +76,13 @@ typedef struct wm_config {
  * follows them (see wm_op_gemm16_ln) where the batch allows; results are bit-identical either way.  Off by default:
  * measured +0.5 % tiles/s on ViT-H B=4 (the GEMMs are power-limited).  Also: env WM_LN_FUSE=1. */
 #define WM_CFG_FUSE_LN 1
+/* WM_CFG_FOLD_LN (round 3): the blocks' two LayerNorms run inside the GEMMs around them -- the residual GEMM's epilogue also
+ * produces each row's statistics and a 16-bit copy of the row, the following qkv / lin1 GEMM multiplies that copy with
+ * gamma (.) W and applies rstd (acc - mean c1) + c2 in its epilogue (csrc/gemm16_v5.h "Folded LayerNorm") -- so the residual
+ * stream is not re-read by a LayerNorm kernel.  Results differ from the unfolded path within the operand rounding (the
+ * rounding points move), they do not depend on the batch size.  Also: env WM_LN_FOLD=1 (Python side).  Takes precedence over
+ * WM_CFG_FUSE_LN. */
+#define WM_CFG_FOLD_LN 2
 
 typedef struct wm_handle wm_handle;
 
@@ -224,7 +231,9 @@ int wm_profile_read(wm_handle* h, wm_kclass_stat* out /* [WM_KCLASS_COUNT] */);
 #define WM_GEMM_V5_256_LNF 10   /* gemm16v5_kernel<256> + fused LayerNorm */
 #define WM_GEMM_FP8_320 11      /* gemm8_kernel<320>: MX-fp8 block-scaled MFMA (WM_PREC_FP8) */
 #define WM_GEMM_FP8_256 12      /* gemm8_kernel<256> */
-#define WM_GEMM_VARIANT_COUNT 13
+#define WM_GEMM_V5_320_FOLDP 13 /* gemm16v5_kernel<320> fp32 + residual + row statistics + 16-bit copy (folded LayerNorm, producer) */
+#define WM_GEMM_V5_256_FOLDP 14
+#define WM_GEMM_VARIANT_COUNT 15
 int wm_debug_gemm_variant_counts(int64_t* out /* [WM_GEMM_VARIANT_COUNT] */, int n);
 int wm_debug_reset_gemm_variant_counts(void);
 
@@ -271,6 +280,23 @@ int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* bias_dev,
                  const float* residual_dev, int res_mod, float* out_f32_dev, void* out_16_dev,
                  int M, int N, int K, int act, int precision, void* stream);
 int wm_op_gemm16_takes_packed(int M, int N, int K);
+
+/* Folded LayerNorm, the three pieces as single ops (kernel-level parity tests; the engine uses them under WM_CFG_FOLD_LN).
+ * wm_op_ln_stats16: x [rows][C] fp32 -> stats [rows][C / BN][2] = per-row (mean, M2) over column tiles of BN = 320 (C % 320 == 0)
+ *   or 256 columns, and x16 = the rows as 16-bit in LDS-image order (rows % 16 == 0, C / BN <= 4).
+ * wm_op_fold_weight16: w16 [N][K] 16-bit row-major, gamma / beta [K], bias [N] (may be NULL) -> wf = round16(gamma (.) w16) in
+ *   LDS-image order, c1[n] = sum_k wf[n][k], c2[n] = sum_k beta[k] w16[n][k] + bias[n].
+ * wm_op_gemm16_folded: out16 = act(rstd (x16 wf^T - mean c1) + c2) with (mean, rstd) combined per row from `stats`
+ *   = act(LayerNorm(x; gamma, beta, eps) w16^T + bias) up to operand rounding; act 0 | 1 (GELU), optional WM_GEMM_OUT_PACKED.
+ * wm_op_gemm16_stats: out_f32 = residual + a w^T + bias (may alias), plus stats and x16 of out_f32 as wm_op_ln_stats16
+ *   writes them (bit-identical: same arithmetic); `layout`: WM_GEMM_W_PACKED | WM_GEMM_A_PACKED. */
+int wm_op_ln_stats16(const float* x_dev, float* stats_dev, void* x16_dev, int64_t rows, int C, int precision, void* stream);
+int wm_op_fold_weight16(const void* w16_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev, void* wf_dev,
+                        float* c1_dev, float* c2_dev, int N, int K, int precision, void* stream);
+int wm_op_gemm16_folded(const void* x16_dev, const void* wf_dev, const float* c1_dev, const float* c2_dev, const float* stats_dev,
+                        float eps, void* out_16_dev, int M, int N, int K, int act, int precision, void* stream);
+int wm_op_gemm16_stats(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev, float* out_f32_dev,
+                       void* x16_dev, float* stats_dev, int M, int N, int K, int layout, int precision, void* stream);
 int wm_op_pack16(const void* in_dev, void* out_dev, int64_t rows, int K, void* stream);
 
 /* fp8 (OCP e4m3) GEMM of WM_PREC_FP8, gemm8.h: C = act((A W^T) * wscale[n] + bias[n]) (+ residual).

@@ -60,6 +60,16 @@ struct Gemm16Args {
     // gemm16_v5.h only: W / A stored in LDS-image order ([rows / 16][K / 32][64 x 16 B], pack16_lds_image_kernel); out_packed:
     // the 16-bit output is written in that order (it is the next GEMM's A operand; N % 32 == 0)
     int w_packed, a_packed, out_packed;
+    // Folded LayerNorm (gemm16_v5.h "Folded LayerNorm").  Producer (FOLDP instance, fp32 + residual epilogue): st_stats
+    // [M][N / BN][2] receives each row's (mean, M2) over this tile's columns, out16 the finished rows as 16-bit in LDS-image
+    // order.  Consumer (16-bit epilogue): A is such a 16-bit copy x16 and W = gamma (.) W; with fold_stats = the producer's
+    // partials over fold_ntile tiles of fold_bn columns (fold_ntile * fold_bn = K), fold_c1[n] = sum_k W[n][k] and
+    // bias[n] = sum_k beta[k] W0[n][k] + b[n] the epilogue computes rstd (acc - mean c1) + bias = LayerNorm(x) W0^T + b.
+    float* st_stats;
+    const float* fold_stats;
+    const float* fold_c1;
+    int fold_ntile;
+    float fold_bn, fold_eps;
 };
 
 template <class T>

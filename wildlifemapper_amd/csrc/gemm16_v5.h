@@ -45,7 +45,22 @@ namespace wm {
 // (LayerNorm, the GELU epilogue below with `out_packed`).  Same bytes in the same LDS places: results are bit-identical.
 // (Also measured in round 3 and archived, tools/experiments/gemm16_v5_wdirect.h: W fragments loaded straight into registers,
 // bypassing the ring: 1.44x slower from row-major W, 1.07x slower from fragment-packed W.)
-template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false>
+//
+// Folded LayerNorm (round 3).  The blocks' LayerNorms were a kernel of their own that re-read the fp32 residual stream the
+// residual GEMM had just written (6 % of a step).  LN(x) W^T + b = rstd (x (gamma (.) W)^T - mean c1) + c2 with c1[n] = sum_k
+// (gamma W)[n][k], c2[n] = sum_k beta[k] W[n][k] + b[n], so the normalisation moves into the CONSUMER's epilogue and the
+// statistics into the PRODUCER's:
+//   FOLDP instance (proj, lin2, the stem's proj_back): the fp32 + residual epilogue, with a 16-lane group owning a row of the
+//     pass, also computes the row's (mean, M2) over this tile's BN columns (two-pass, ln_partial16: the arithmetic of
+//     layernorm_tiled_kernel) -> st_stats[m][tile], and writes the finished rows as 16-bit in LDS-image order -> out16 (x16);
+//   consumer (qkv, lin1; fold_stats != null): the row block's partials (256 rows x fold_ntile x 8 B, contiguous) come in by
+//     one LDS-DMA piece per wave in front of the ring fill, 256 threads combine them (ln_combine, Chan) after the K loop, and
+//     the 16-bit epilogue applies rstd (acc - mean c1) + c2 before the activation.
+// No workgroup waits for another one (the hand-off is the kernel boundary), unlike the LNF instance.  The operand is the RAW
+// residual in 16 bits: its rounding error relative to LN's input scale is what rounding the normalised value costs, as long
+// as a row's mean is not large against its spread (it is not: per-token means of the stream are O(0.1 sigma), outlier profile
+// included); fp16's range holds for |x| < 65504 (the saturation census watches this buffer).
+template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false, bool FOLDP = false>
 __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     using C = G3<BN, 4>;
     constexpr int AHEAD = NSLOT - 1;                       // K-steps of DMA in flight
@@ -188,6 +203,15 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.residual) res_dma(0);
+    constexpr int FOLD_RAW = LDS_TOTAL - RES_BYTES, FOLD_MR = FOLD_RAW + 8192;      // landing buffer 0 is idle without a residual
+    if constexpr (!LNF && !FOLDP) {
+        if (p.fold_stats) {
+            // the row block's partial statistics: 256 rows x fold_ntile x (mean, M2), contiguous; one DMA piece per wave
+            if (wave * 1024 < 256 * p.fold_ntile * 8)
+                __builtin_amdgcn_global_load_lds((const char*)(p.fold_stats + (size_t)m0 * p.fold_ntile * 2) + wave * 1024 + lane * 16,
+                                                 WM_LDS_PTR(smem + FOLD_RAW + wave * 1024), 16, 0, 0);
+        }
+    }
 
     if (wr == 0) {
         using EX = std::integral_constant<bool, (C::W_REM > 0)>;
@@ -255,15 +279,49 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
 #pragma unroll
     for (int ni = 0; ni < C::NT; ++ni)
         bias_v[ni] = p.bias ? *(const f32x4*)(p.bias + n0 + wc * C::WCOLS + ni * 16 + fq_e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 c1_v[C::NT];
+    if constexpr (!LNF && !FOLDP) {
+        if (p.fold_stats) {
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni) c1_v[ni] = *(const f32x4*)(p.fold_c1 + n0 + wc * C::WCOLS + ni * 16 + fq_e * 4);
+            if (tid < C::BM) {                              // one row per thread: Chan combination of its column-tile partials
+                const float2* raw = (const float2*)(smem + FOLD_RAW) + tid * p.fold_ntile;
+                float mk[8], qk[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    mk[i] = qk[i] = 0.f;
+                    if (i < p.fold_ntile) { const float2 t = raw[i]; mk[i] = t.x; qk[i] = t.y; }
+                }
+                float rstd;
+                const float mean = ln_combine(mk, qk, p.fold_ntile, p.fold_bn, (float)p.K, p.fold_eps, rstd);
+                *(float2*)(smem + FOLD_MR + tid * 8) = make_float2(mean, rstd);
+            }
+        }
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): this wave's fragment reads are back
     barrier();                                              // every wave is done with the ring
     if constexpr (DBG) we[0] = wall_clock64();
+    float2 row_mr[C::MT];                                   // fold: (mean, rstd) of this lane's row of every row fragment
+    if constexpr (!LNF && !FOLDP) {
+        if (p.fold_stats) {
+#pragma unroll
+            for (int mi = 0; mi < C::MT; ++mi) row_mr[mi] = *(const float2*)(smem + FOLD_MR + (wr * 128 + mi * 16 + fr_e) * 8);
+        }                                                   // (the epilogue's staging never touches FOLD_RAW / FOLD_MR)
+    }
     // one straight-line instance per activation (a per-fragment runtime branch costs more than the stores)
-    auto epilogue = [&](auto act_tag) {
+    auto epilogue = [&](auto act_tag, auto fold_tag) {
     constexpr int ACT = decltype(act_tag)::value;
+    constexpr bool FOLD = decltype(fold_tag)::value;
     const int tid = tid_e, fr = fr_e, fq = fq_e;           // shadow the kernel-scope values (see tid_e)
-    auto finish = [&](f32x4 v, int ni) {
-        v += bias_v[ni];
+    auto finish = [&](f32x4 v, int ni, int mi = 0) {
+        if constexpr (FOLD) {
+            // LayerNorm folded into this GEMM: rstd (acc - mean c1) + c2, c2 arriving as the bias
+            const float mean = row_mr[mi].x, rstd = row_mr[mi].y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(fmaf(-mean, c1_v[ni][j], v[j]), rstd, bias_v[ni][j]);
+        } else {
+            v += bias_v[ni];
+        }
         if constexpr (ACT == ACT_GELU) {
             v = gelu_erf_fast4(v);
         } else if constexpr (ACT == ACT_RELU) {
@@ -272,6 +330,46 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         }
         return v;
     };
+    if constexpr (FOLDP) {
+        // ---- fp32 + residual, per-row partial LayerNorm statistics, 16-bit copy in LDS-image order (see "Folded LayerNorm") ----
+        constexpr int ROWB = BN * 4 + 16, CPT = RP_CPR / 16;
+        const int r = tid >> 4, l16 = tid & 15;              // row of the pass, position in the row's 16-lane group
+        const int ntile = p.N / BN, nt = n0 / BN;
+#pragma unroll
+        for (int q = 0; q < C::MT; ++q) {
+            if (q + 1 < C::MT) res_dma(q + 1);
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni)
+                *(f32x4*)(smem + RES_STG + (wr * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 4) = finish(acc[q][ni], ni);
+            if (q + 1 < C::MT) wait_vmcnt<RP_PW>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            barrier();
+            const char* land = smem + ((q & 1) ? RES_L1 : RES_L0);
+            const int m = m0 + (r >> 4) * 128 + q * 16 + (r & 15);
+            f32x4 v[CPT];
+#pragma unroll
+            for (int kk = 0; kk < CPT; ++kk) {
+                const int ch = l16 + 16 * kk;
+                v[kk] = *(const f32x4*)(smem + RES_STG + r * ROWB + ch * 16) + *(const f32x4*)(land + (r * RP_CPR + ch) * 16);
+                *(f32x4*)(p.out32 + (size_t)m * p.N + n0 + ch * 4) = v[kk];
+            }
+            float mean, m2;
+            ln_partial16<CPT>(v, 1.0f / BN, mean, m2);
+            if (l16 == 0) *(float2*)(p.st_stats + ((size_t)m * ntile + nt) * 2) = make_float2(mean, m2);
+            // a wave holds 4 consecutive rows: per K-step of the copy its 16 lanes x 4 rows write 256 contiguous bytes
+#pragma unroll
+            for (int kk = 0; kk < CPT; ++kk) {
+                typename T::vec4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[kk][j]);
+                *(typename T::vec4*)(p.out16 + lds_image_index(m, n0 + (l16 + 16 * kk) * 4, p.N)) = o;
+            }
+            if (q + 1 < C::MT) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                barrier();
+            }
+        }
+    } else
     if constexpr (LNF) {
         // ---- residual + LayerNorm (proj -> norm2, lin2 -> the next block's norm1; image_encoder.py:200-203) ----
         // The separate LayerNorm kernel re-read the 84 MB fp32 residual stream this epilogue has just produced.  Here a
@@ -391,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             for (int mm = 0; mm < MTP; ++mm)
 #pragma unroll
                 for (int ni = 0; ni < C::NT; ++ni) {
-                    const f32x4 v = finish(acc[q * MTP + mm][ni], ni);
+                    const f32x4 v = finish(acc[q * MTP + mm][ni], ni, q * MTP + mm);
                     typename T::vec4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
@@ -492,12 +590,15 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         }
     }
     };
-    if constexpr (LNF) {
-        epilogue(std::integral_constant<int, ACT_NONE>{});
+    if constexpr (LNF || FOLDP) {
+        epilogue(std::integral_constant<int, ACT_NONE>{}, std::false_type{});
     } else {
-        if (act == ACT_GELU) epilogue(std::integral_constant<int, ACT_GELU>{});
-        else if (act == ACT_RELU) epilogue(std::integral_constant<int, ACT_RELU>{});
-        else epilogue(std::integral_constant<int, ACT_NONE>{});
+        if (p.fold_stats) {                                  // folded LayerNorm: the 16-bit-output GEMMs qkv (no activation) and lin1 (GELU)
+            if (act == ACT_GELU) epilogue(std::integral_constant<int, ACT_GELU>{}, std::true_type{});
+            else epilogue(std::integral_constant<int, ACT_NONE>{}, std::true_type{});
+        } else if (act == ACT_GELU) epilogue(std::integral_constant<int, ACT_GELU>{}, std::false_type{});
+        else if (act == ACT_RELU) epilogue(std::integral_constant<int, ACT_RELU>{}, std::false_type{});
+        else epilogue(std::integral_constant<int, ACT_NONE>{}, std::false_type{});
     }
     if constexpr (DBG) {
         if (wave == 0) {

@@ -83,15 +83,6 @@ __device__ __forceinline__ void store4_as(void* base, int64_t elem, const f32x4&
     }
 }
 
-// Element index of (row, col) of a [rows][C] 16-bit operand stored in LDS-image order (gemm16_v5.h "Operand layout"):
-// [rows / 16][C / 32][64 positions x 8 elements], position = (row % 16) * 4 + (chunk ^ ((-((row % 16) >> 2)) & 3)),
-// chunk = (col % 32) / 8.  rows % 16 == 0, C % 32 == 0.
-__device__ __forceinline__ int64_t lds_image_index(int64_t row, int col, int C) {
-    const int r = (int)(row & 15), cw = col & 31;
-    const int pos = r * 4 + ((cw >> 3) ^ ((0 - (r >> 2)) & 3));
-    return ((row >> 4) * (C >> 5) + (col >> 5)) * 512 + pos * 8 + (cw & 7);
-}
-
 // row-major [rows][K] 16-bit -> LDS-image order (weights at wm_finalize_weights; tests).  One thread per 16-byte chunk.
 __global__ __launch_bounds__(256) void pack16_lds_image_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t rows, int K) {
     const int64_t n16 = rows * (K / 8);
@@ -168,6 +159,70 @@ __global__ __launch_bounds__(256) void layernorm_tiled_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = ln_apply(v[kk][j], mean, rstd, g[j], b[j]);
         store4_as<T>(out16, row * C + c0, y);
+    }
+}
+
+// Folded LayerNorm, weight side (once per wm_finalize_weights): from the 16-bit weight W16 [N][K] (row-major, as packed for
+// the classic path), the LayerNorm's gamma / beta [K] and the Linear's bias [N]:
+//   wf[n][k] = round16(gamma[k] * W16[n][k])   written in LDS-image order
+//   c1[n] = sum_k wf[n][k]        c2[n] = sum_k beta[k] * W16[n][k] + bias[n]
+// One workgroup per output row; fixed summation order (thread-strided partials, then a fixed tree): the same bits every time.
+template <class T>
+__global__ __launch_bounds__(256) void fold_weight_kernel(const u16* __restrict__ w16, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ bias, u16* __restrict__ wf, float* __restrict__ c1,
+                                                          float* __restrict__ c2, int N, int K) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red[2][256];
+    float s1 = 0.f, s2 = 0.f;
+    for (int k4 = tid; k4 < K / 4; k4 += 256) {
+        const typename T::vec4 w = *(const typename T::vec4*)(w16 + (size_t)n * K + k4 * 4);
+        const f32x4 g = *(const f32x4*)(gamma + k4 * 4), b = *(const f32x4*)(beta + k4 * 4);
+        typename T::vec4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float wv = T::to_f32(w[j]);
+            o[j] = T::from_f32(g[j] * wv);
+            s1 += T::to_f32(o[j]);
+            s2 = fmaf(b[j], wv, s2);
+        }
+        *(typename T::vec4*)(wf + lds_image_index(n, k4 * 4, K)) = o;
+    }
+    red[0][tid] = s1; red[1][tid] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { c1[n] = red[0][0]; c2[n] = red[1][0] + (bias ? bias[n] : 0.f); }
+}
+
+// Folded LayerNorm (gemm16_v5.h "Folded LayerNorm"), standalone producer: per-row partial statistics over BN-column tiles,
+// [rows][C / BN][2] = (mean, M2) -- the same arithmetic, lane assignment and order as the residual GEMM's FOLDP epilogue and
+// as layernorm_tiled_kernel above -- and the 16-bit copy of the rows in LDS-image order.  Used where the residual stream was
+// not produced by a FOLDP launch: a half-width GEMM (one or two tiles per call), or an operand-type boundary between blocks.
+template <class T, int BN>
+__global__ __launch_bounds__(256) void ln_stats_x16_kernel(const float* __restrict__ x, float* __restrict__ stats, u16* __restrict__ x16,
+                                                           int64_t rows, int C) {
+    constexpr int CPT = BN / 64;
+    const int lane = threadIdx.x & 63, k = lane >> 4, l16 = lane & 15;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int ntile = C / BN;
+    const bool live = k < ntile;
+    const float* xr = x + row * C + k * BN;
+    f32x4 v[CPT];
+#pragma unroll
+    for (int kk = 0; kk < CPT; ++kk) v[kk] = live ? *(const f32x4*)(xr + (l16 + 16 * kk) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float pm, pq;
+    ln_partial16<CPT>(v, 1.0f / BN, pm, pq);
+    if (!live) return;
+    if (l16 == 0) *(float2*)(stats + (row * ntile + k) * 2) = make_float2(pm, pq);
+#pragma unroll
+    for (int kk = 0; kk < CPT; ++kk) {
+        typename T::vec4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[kk][j]);
+        *(typename T::vec4*)(x16 + lds_image_index(row, k * BN + (l16 + 16 * kk) * 4, C)) = o;
     }
 }
 

@@ -225,6 +225,12 @@ struct wm_handle {
     std::map<std::string, std::vector<int64_t>> expected;   // name -> shape
     std::map<std::string, HostW> staged;
     std::map<std::string, uint16_t*> w16;
+    // folded LayerNorm (WM_CFG_FOLD_LN): per consumer GEMM weight name: gamma (.) W in LDS-image order, c1, c2; per-row partial
+    // statistics of the residual stream [maxB * 4096][<= 4][2]
+    std::map<std::string, uint16_t*> wfold;
+    std::map<std::string, float*> fold_c1, fold_c2;
+    float* fold_stats = nullptr;
+    bool fold = false;
     std::map<std::string, uint16_t*> w16p;  // the same weights in LDS-image order (gemm16_v5.h "Operand layout"), for the 256-row-tile kernels
     std::map<std::string, uint8_t*> w8;     // WM_PREC_FP8: e4m3 weights of the blocks' GEMMs; their per-channel scales live in w32[name + ".wscale"]
     uint8_t* ao8 = nullptr;                 // attention output as e4m3 (A operand of proj)
@@ -535,11 +541,46 @@ static bool gemm16_takes_v5(int M, int N, int K) {
     return false;
 }
 
-// Wp: the weight in LDS-image order (or null); a_packed / out_packed: A is / the 16-bit output shall be in that order.  Packed
-// operands exist only for the gemm16_v5 kernel: the caller asks gemm16_takes_v5 first, a mismatch is an error.
+// Options of a launch that only the gemm16_v5 kernel has (the caller asks gemm16_takes_v5 first; a mismatch is an error):
+//   Wp: the weight in LDS-image order (or null); a_packed / out_packed: A is / the 16-bit output shall be in that order;
+//   st_stats: folded-LayerNorm PRODUCER (fp32 + residual form): per-row partial statistics out, out16 = 16-bit copy of the
+//             rows in LDS-image order;
+//   fold_stats / fold_c1 / fold_eps: folded-LayerNorm CONSUMER (16-bit-only form): A = such a copy, W = gamma (.) W, bias = c2.
+struct GemmExtra {
+    const void* Wp = nullptr;
+    int a_packed = 0, out_packed = 0;
+    float* st_stats = nullptr;
+    const float* fold_stats = nullptr;
+    const float* fold_c1 = nullptr;
+    float fold_eps = 0.f;
+};
+static GemmExtra GX(const void* Wp, int a_packed = 0, int out_packed = 0) {
+    GemmExtra x;
+    x.Wp = Wp; x.a_packed = a_packed; x.out_packed = out_packed;
+    return x;
+}
+// column-tile width of the folded LayerNorm's partial statistics over C channels (the producer GEMM's tile width at N = C)
+static int fold_bn_for(int C) { return C % 320 == 0 ? 320 : 256; }
+
+template <class T16, int BN>
+int launch_gemm16v5_foldp_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
+    using G = G3<BN, 4>;
+    constexpr int LDS = 3 * G::STAGE + 32 * BN * 4;
+    WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, false, true>, LDS));
+    count_variant(BN == 320 ? WM_GEMM_V5_320_FOLDP : WM_GEMM_V5_256_FOLDP);
+    const int grid = (a.M / 256) * (a.N / BN);
+    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
+               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + 10.0 * a.M * a.N);
+    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, false, true>), dim3(grid), dim3(512), LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias,
                   const float* res, int res_mod, float* out32, void* out16, int M, int N, int K, int act,
-                  const void* Wp = nullptr, int a_packed = 0, int out_packed = 0) {
+                  const GemmExtra& x = GemmExtra{}) {
+    const void* Wp = x.Wp;
+    const int a_packed = x.a_packed, out_packed = x.out_packed;
     if (M <= 0 || N <= 0 || K <= 0 || M % G16_BM || N % G16_BN || K % G16_BK)
         return fail("gemm16: shape M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, G16_BM, G16_BN, G16_BK);
     if (!out32 && !out16) return fail("gemm16: no output");
@@ -549,10 +590,24 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
         a.a_packed = a_packed;
         a.out_packed = out_packed;
         if (out_packed && (out32 || res || !out16)) return fail("gemm16: a packed output is the 16-bit-only form (no fp32 output, no residual)");
+        if (x.st_stats) {                   // folded LayerNorm, producer
+            if (!res || !out32 || !out16 || act != ACT_NONE || N / (N % 320 == 0 ? 320 : 256) > 4)
+                return fail("gemm16: the statistics-producing form is fp32 + residual with a 16-bit copy, no activation, at most 4 column tiles");
+            a.st_stats = x.st_stats;
+            if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_foldp_t<BF16, 320>(h, s, a)), (launch_gemm16v5_foldp_t<FP16, 320>(h, s, a)));
+            return WM_BY_PREC((launch_gemm16v5_foldp_t<BF16, 256>(h, s, a)), (launch_gemm16v5_foldp_t<FP16, 256>(h, s, a)));
+        }
+        if (x.fold_stats) {                 // folded LayerNorm, consumer
+            const int bn = fold_bn_for(K);
+            if (out32 || res || !out16 || !x.fold_c1 || !bias || (act != ACT_NONE && act != ACT_GELU) || K % bn || K / bn > 4)
+                return fail("gemm16: the folded-LayerNorm form is 16-bit-only output, act none | GELU, K a multiple of %d with at most 4 tiles", bn);
+            a.fold_stats = x.fold_stats; a.fold_c1 = x.fold_c1; a.fold_ntile = K / bn; a.fold_bn = (float)bn; a.fold_eps = x.fold_eps;
+        }
         if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320>(h, s, a)), (launch_gemm16v5_t<FP16, 320>(h, s, a)));
         return WM_BY_PREC((launch_gemm16v5_t<BF16, 256>(h, s, a)), (launch_gemm16v5_t<FP16, 256>(h, s, a)));
     }
-    if (a_packed || out_packed) return fail("gemm16: M=%d N=%d K=%d runs on a half-width kernel, which takes row-major operands only", M, N, K);
+    if (a_packed || out_packed || x.st_stats || x.fold_stats)
+        return fail("gemm16: M=%d N=%d K=%d runs on a half-width kernel, which takes row-major operands only", M, N, K);
     if (M % 256 == 0) {
         // half-width tiles: 256 x 160 where N allows and it fills the last round at least as well as 256 x 128
         const bool can160 = N % 160 == 0;
@@ -997,6 +1052,7 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     h->fp8_bf16_tail = getenv("WM_FP8_BF16_TAIL") ? atoi(getenv("WM_FP8_BF16_TAIL")) : 0;
     h->fp8_bf16_head = getenv("WM_FP8_BF16_HEAD") ? atoi(getenv("WM_FP8_BF16_HEAD")) : 0;
     h->row_major = getenv("WM_ROW_MAJOR_OPERANDS") && atoi(getenv("WM_ROW_MAJOR_OPERANDS")) != 0;
+    h->fold = (cfg->flags & WM_CFG_FOLD_LN) != 0 && !h->row_major;
     h->fp8_gemms = cfg->fp8_gemms ? (cfg->fp8_gemms & WM_FP8_ALL) : (getenv("WM_FP8_GEMMS") ? (atoi(getenv("WM_FP8_GEMMS")) & WM_FP8_ALL) : WM_FP8_ALL);
     if (cfg->precision == WM_PREC_FP8 && h->fp8_gemms == 0) { delete h; return fail("wm_create: fp8_gemms selects no GEMM"); }
     h->D = cfg->embed_dim; h->depth = cfg->depth; h->heads = cfg->num_heads; h->hd = hd;
@@ -1029,6 +1085,7 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     A(kpe, (size_t)T * OUTC * 4);
     A(records, B * NQ * sizeof(wm_box_record));
     A(sat_counts, WM_SAT_COUNT * sizeof(unsigned long long));
+    A(fold_stats, BT * 4 * 2 * 4);
 #undef A
     if (r) { wm_destroy(h); return r; }
     // FFT twiddles exp(-2 pi i k / 1024), computed in double
@@ -1171,8 +1228,35 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
             }
         HIP_TRY(hipMemcpy(h->kpe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
     }
+    // Folded LayerNorm: gamma (.) W (LDS-image order), c1, c2 of every block's qkv (norm1) and lin1 (norm2), from the DEVICE
+    // copies (the 16-bit row-major weight as packed above), so a later partial re-upload folds to the same bits as a full one.
+    if (h->fold && h->enc_ready) {
+        for (int i = 0; i < h->depth; ++i) {
+            const std::string b = "image_encoder.blocks." + std::to_string(i) + ".";
+            const int P = block_prec(h, i) == WM_PREC_FP8 ? WM_PREC_BF16 : block_prec(h, i);
+            const std::pair<const char*, const char*> pairs[] = {{"attn.qkv", "norm1"}, {"mlp.lin1", "norm2"}};
+            for (const auto& pr : pairs) {
+                const std::string wn = b + pr.first + ".weight";
+                if (!h->w16.count(wn)) continue;            // an fp8 GEMM of this block: no 16-bit weight, no fold
+                const int N = (int)h->expected.at(wn)[0], K = (int)h->expected.at(wn)[1];
+                if (!h->wfold.count(wn)) {
+                    uint16_t* wf = nullptr; float *c1 = nullptr, *c2 = nullptr;
+                    WM_TRY(dalloc(h, &wf, (size_t)N * K * 2)); WM_TRY(dalloc(h, &c1, (size_t)N * 4)); WM_TRY(dalloc(h, &c2, (size_t)N * 4));
+                    h->wfold[wn] = wf; h->fold_c1[wn] = c1; h->fold_c2[wn] = c2;
+                }
+                const float* g = h->w32.at(b + pr.second + ".weight");
+                const float* be = h->w32.at(b + pr.second + ".bias");
+                const float* bias = h->w32.at(b + pr.first + ".bias");
+                if (P == WM_PREC_FP16)
+                    hipLaunchKernelGGL(fold_weight_kernel<FP16>, dim3(N), dim3(256), 0, 0, (const u16*)h->w16.at(wn), g, be, bias, (u16*)h->wfold[wn], h->fold_c1[wn], h->fold_c2[wn], N, K);
+                else
+                    hipLaunchKernelGGL(fold_weight_kernel<BF16>, dim3(N), dim3(256), 0, 0, (const u16*)h->w16.at(wn), g, be, bias, (u16*)h->wfold[wn], h->fold_c1[wn], h->fold_c2[wn], N, K);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+    }
     (void)D;
-    HIP_TRY(hipDeviceSynchronize());        // the pack launches above
+    HIP_TRY(hipDeviceSynchronize());        // the pack / fold launches above
     h->staged.clear();
     h->finalized = true;
     return 0;
@@ -1220,6 +1304,24 @@ int fft_impl(wm_handle* h, const float* x, float* out, int B, hipStream_t s) {
     return 0;
 }
 
+// Folded LayerNorm, standalone producer (ln_stats_x16_kernel): partial statistics + 16-bit copy of `rows` fp32 rows of C channels
+int launch_ln_stats16(wm_handle* h, hipStream_t s, int prec, const float* x, float* stats, void* x16, int64_t rows, int C) {
+    const int bn = fold_bn_for(C);
+    if (C % bn || C / bn > 4 || rows % 16 || C % 32 || (prec != WM_PREC_FP16 && prec != WM_PREC_BF16))
+        return fail("ln_stats16: rows=%lld C=%d precision %d unsupported", (long long)rows, C, prec);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    Bracket br(h, s, WM_KCLASS_LAYERNORM, 0.0, (double)rows * C * 6.0);
+    if (bn == 320) {
+        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((ln_stats_x16_kernel<FP16, 320>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C);
+        else hipLaunchKernelGGL((ln_stats_x16_kernel<BF16, 320>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C);
+    } else {
+        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((ln_stats_x16_kernel<FP16, 256>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C);
+        else hipLaunchKernelGGL((ln_stats_x16_kernel<BF16, 256>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // opt-in census of clamped values in a 16-bit / e4m3 activation buffer (wm_debug_saturation_enable); prec = element type
 int sat_check(wm_handle* h, hipStream_t s, int which, const void* buf, int64_t n_elems, int prec) {
     if (!h->sat_on) return 0;
@@ -1243,36 +1345,51 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     WM_TRY(launch_simple(h, s, B * 6.3e6, patchify_kernel<FP16>, dim3(grid_for((int64_t)B * 1024 * 256)), dim3(256), hfc, (u16*)h->h16, B, 1));
     // t = patch_embed(x) + pos_embed  -> tokbase (fp32) and xn16 (16-bit copy for proj_patch)
     WM_TRY(launch_gemm16(h, s, PS, h->p16, W16(h, e + "patch_embed.proj.weight"), W32(h, e + "patch_embed.proj.bias"),
-                         W32(h, e + "pos_embed"), T, h->tokbase, h->xn16, M, D, 768, ACT_NONE, W16P(h, e + "patch_embed.proj.weight")));
+                         W32(h, e + "pos_embed"), T, h->tokbase, h->xn16, M, D, 768, ACT_NONE, GX(W16P(h, e + "patch_embed.proj.weight"))));
     WM_TRY(do_tap(h, s, -3, B, h->tokbase));
     WM_TRY(launch_gemm16(h, s, PS, h->h16, W16(h, e + "hfc_embed.proj.weight"), W32(h, e + "hfc_embed.proj.bias"),
-                         nullptr, 0, nullptr, h->he16, M, HFC, 256, ACT_NONE, W16P(h, e + "hfc_embed.proj.weight")));
+                         nullptr, 0, nullptr, h->he16, M, HFC, 256, ACT_NONE, GX(W16P(h, e + "hfc_embed.proj.weight"))));
     // ---- HFC adaptor (image_encoder.py:486-516) ----
     WM_TRY(launch_gemm16(h, s, PS, h->he16, W16(h, a + "proj_hfc.weight"), W32(h, a + "proj_hfc.bias"),
-                         W32(h, a + "pos_embed"), T, nullptr, h->hp16, M, HFC, HFC, ACT_NONE, W16P(h, a + "proj_hfc.weight")));                    // :494
+                         W32(h, a + "pos_embed"), T, nullptr, h->hp16, M, HFC, HFC, ACT_NONE, GX(W16P(h, a + "proj_hfc.weight"))));                    // :494
     WM_TRY(launch_gemm16(h, s, PS, h->xn16, W16(h, a + "proj_patch.weight"), W32(h, a + "proj_patch.bias"),
-                         nullptr, 0, h->pt32, h->pt16, M, HFC, D, ACT_NONE, W16P(h, a + "proj_patch.weight")));                                       // :495
+                         nullptr, 0, h->pt32, h->pt16, M, HFC, D, ACT_NONE, GX(W16P(h, a + "proj_patch.weight"))));                                       // :495
     const uint16_t* wi = W16(h, a + "cross_attn.in_proj_weight");
     const uint16_t* wip = W16P(h, a + "cross_attn.in_proj_weight");      // same element offsets: 16 rows x K are one contiguous block in both layouts
     const float* bi = W32(h, a + "cross_attn.in_proj_bias");
-    WM_TRY(launch_gemm16(h, s, PS, h->pt16, wi, bi, nullptr, 0, nullptr, h->q16, M, HFC, HFC, ACT_NONE, wip));
-    WM_TRY(launch_gemm16(h, s, PS, h->hp16, wi + (size_t)HFC * HFC, bi + HFC, nullptr, 0, nullptr, h->kv16, M, 2 * HFC, HFC, ACT_NONE,
-                         wip ? wip + (size_t)HFC * HFC : nullptr));
+    WM_TRY(launch_gemm16(h, s, PS, h->pt16, wi, bi, nullptr, 0, nullptr, h->q16, M, HFC, HFC, ACT_NONE, GX(wip)));
+    WM_TRY(launch_gemm16(h, s, PS, h->hp16, wi + (size_t)HFC * HFC, bi + HFC, nullptr, 0, nullptr, h->kv16, M, 2 * HFC, HFC, ACT_NONE, GX(wip ? wip + (size_t)HFC * HFC : nullptr)));
     WM_TRY(launch_mha16(h, s, PS, h->q16, HFC, h->kv16, 2 * HFC, h->kv16 + HFC, 2 * HFC, h->aoh16, HFC, B, HFC_HEADS,
                         HFC / HFC_HEADS, T, T));                                                                      // :500-503
     WM_TRY(launch_gemm16(h, s, PS, h->aoh16, W16(h, a + "cross_attn.out_proj.weight"), W32(h, a + "cross_attn.out_proj.bias"),
-                         h->pt32, 0, h->y1, nullptr, M, HFC, HFC, ACT_NONE, W16P(h, a + "cross_attn.out_proj.weight")));                                       // + residual :504
+                         h->pt32, 0, h->y1, nullptr, M, HFC, HFC, ACT_NONE, GX(W16P(h, a + "cross_attn.out_proj.weight"))));                                       // + residual :504
     WM_TRY(launch_layernorm(h, s, PS, h->y1, W32(h, a + "norm1.weight"), W32(h, a + "norm1.bias"), 1e-5f, h->y1n32, h->y1n16, M, HFC));
     WM_TRY(launch_gemm16(h, s, PS, h->y1n16, W16(h, a + "linear1.weight"), W32(h, a + "linear1.bias"), nullptr, 0, nullptr,
-                         h->h1_16, M, HFC, HFC, ACT_RELU, W16P(h, a + "linear1.weight")));
+                         h->h1_16, M, HFC, HFC, ACT_RELU, GX(W16P(h, a + "linear1.weight"))));
     WM_TRY(launch_gemm16(h, s, PS, h->h1_16, W16(h, a + "linear2.weight"), W32(h, a + "linear2.bias"), h->y1n32, 0, h->z32,
-                         nullptr, M, HFC, HFC, ACT_NONE, W16P(h, a + "linear2.weight")));                                                          // :506-508
+                         nullptr, M, HFC, HFC, ACT_NONE, GX(W16P(h, a + "linear2.weight"))));                                                          // :506-508
     WM_TRY(launch_layernorm(h, s, PS, h->z32, W32(h, a + "norm2.weight"), W32(h, a + "norm2.bias"), 1e-5f, nullptr, h->y2_16, M, HFC));
     // scramble (:512): per tile [4096 tok,1024 ch] re-read as [1024, 4096]; make it the K-contiguous A operand
     WM_TRY(launch_simple(h, s, B * 16.8e6, transpose16_kernel, dim3(T / 64, HFC / 64, B), dim3(256), (const u16*)h->y2_16, (u16*)h->y2t16, HFC, T));
     // x = proj_back(scrambled) + t   (:513-514, :131)
-    WM_TRY(launch_gemm16(h, s, PS, h->y2t16, W16(h, a + "proj_back.weight"), W32(h, a + "proj_back.bias"), h->tokbase, 0,
-                         h->resid, nullptr, M, D, HFC, ACT_NONE, W16P(h, a + "proj_back.weight")));
+    // Folded LayerNorm (WM_CFG_FOLD_LN; gemm16_v5.h "Folded LayerNorm"): a block whose qkv and lin1 run the 256-row-tile
+    // 16-bit kernel takes its two LayerNorms inside those GEMMs.  raw_prec: the 16-bit type in which xn16 holds the copy of the
+    // CURRENT residual stream (LDS-image order) with fold_stats its per-row partial statistics, or -1.
+    auto fold_block = [&](int i) {
+        const int pb = block_prec(h, i);
+        const std::string b = e + "blocks." + std::to_string(i) + ".";
+        return h->fold && pb != WM_PREC_FP8 && gemm16_takes_v5(M, 3 * D, D) && gemm16_takes_v5(M, 4 * D, D) &&
+               h->wfold.count(b + "attn.qkv.weight") && h->wfold.count(b + "mlp.lin1.weight");
+    };
+    int raw_prec = -1;
+    {
+        GemmExtra xb = GX(W16P(h, a + "proj_back.weight"));
+        const bool produce = fold_block(0) && block_prec(h, 0) == PS && gemm16_takes_v5(M, D, HFC);
+        if (produce) xb.st_stats = h->fold_stats;
+        WM_TRY(launch_gemm16(h, s, PS, h->y2t16, W16(h, a + "proj_back.weight"), W32(h, a + "proj_back.bias"), h->tokbase, 0,
+                             h->resid, produce ? h->xn16 : nullptr, M, D, HFC, ACT_NONE, xb));
+        if (produce) raw_prec = PS;
+    }
     WM_TRY(do_tap(h, s, -1, B));
 
     // ---- transformer blocks (image_encoder.py:188-204) ----
@@ -1296,6 +1413,46 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
         // attention output, stays row-major: a head's 80 columns do not fall on the 32-column pieces.)
         const bool pk_qkv = !h->row_major && !q8 && gemm16_takes_v5(M, 3 * D, D), pk_lin1 = !h->row_major && !m8 && gemm16_takes_v5(M, 4 * D, D);
         const bool pk_lin2 = pk_lin1 && gemm16_takes_v5(M, D, 4 * D);
+        if (fold_block(i)) {
+            // ---- both LayerNorms folded: statistics from the producing residual GEMM (or the standalone kernel where that one is
+            // a half-width launch or of another operand type), normalisation in the consuming GEMM's epilogue ----
+            auto folded = [&](const std::string& wn, int act, int out_packed, void* out, int N) {
+                GemmExtra x = GX(h->wfold.at(wn), 1, out_packed);
+                x.fold_stats = h->fold_stats; x.fold_c1 = h->fold_c1.at(wn); x.fold_eps = 1e-6f;
+                return launch_gemm16(h, s, P, h->xn16, W16(h, wn), h->fold_c2.at(wn), nullptr, 0, nullptr, out, M, N, D, act, x);
+            };
+            if (raw_prec != P) WM_TRY(launch_ln_stats16(h, s, P, h->resid, h->fold_stats, h->xn16, M, D));
+            WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, P));
+            WM_TRY(folded(b + "attn.qkv.weight", ACT_NONE, 0, h->qkv16, 3 * D));
+            WM_TRY(sat_check(h, s, WM_SAT_QKV, h->qkv16, (int64_t)M * 3 * D, P));
+            WM_TRY(launch_encoder_attention(h, s, P, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
+                                            W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14, nullptr));
+            WM_TRY(sat_check(h, s, WM_SAT_ATTN, h->ao16, (int64_t)M * D, P));
+            {
+                GemmExtra x = GX(W16P(h, b + "attn.proj.weight"));
+                const bool produce = gemm16_takes_v5(M, D, D);
+                if (produce) x.st_stats = h->fold_stats;
+                WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
+                                     h->resid, produce ? h->xn16 : nullptr, M, D, D, ACT_NONE, x));
+                raw_prec = produce ? P : -1;
+            }
+            if (raw_prec != P) WM_TRY(launch_ln_stats16(h, s, P, h->resid, h->fold_stats, h->xn16, M, D));
+            WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, P));
+            WM_TRY(folded(b + "mlp.lin1.weight", ACT_GELU, pk_lin2, h->hid16, 4 * D));
+            WM_TRY(sat_check(h, s, WM_SAT_HID, h->hid16, (int64_t)M * 4 * D, P));
+            {
+                GemmExtra x = GX(W16P(h, b + "mlp.lin2.weight"), pk_lin2);
+                const bool produce = i + 1 < h->depth && fold_block(i + 1) && block_prec(h, i + 1) == P && gemm16_takes_v5(M, D, 4 * D);
+                if (produce) x.st_stats = h->fold_stats;
+                WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
+                                     h->resid, produce ? h->xn16 : nullptr, M, D, 4 * D, ACT_NONE, x));
+                raw_prec = produce ? P : -1;
+            }
+            xn_ready = false;
+            WM_TRY(do_tap(h, s, i, B));
+            continue;
+        }
+        raw_prec = -1;
         if (!xn_ready) {
             WM_TRY(launch_layernorm_block(h, s, q8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D, pk_qkv));
             xn_packed = pk_qkv;
@@ -1306,7 +1463,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
                                 nullptr, nullptr, h->qkv16, nullptr, M, 3 * D, D, ACT_NONE));
         else
             WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "attn.qkv.weight"), W32(h, b + "attn.qkv.bias"), nullptr, 0, nullptr,
-                                 h->qkv16, M, 3 * D, D, ACT_NONE, W16P(h, b + "attn.qkv.weight"), xn_packed));
+                                 h->qkv16, M, 3 * D, D, ACT_NONE, GX(W16P(h, b + "attn.qkv.weight"), xn_packed)));
         WM_TRY(sat_check(h, s, WM_SAT_QKV, h->qkv16, (int64_t)M * 3 * D, P));
         // the attention kernels write their output as e4m3 when proj consumes e4m3
         WM_TRY(launch_encoder_attention(h, s, P, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
@@ -1325,7 +1482,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
             if (n2_ready) xn_packed = false;                 // the fused epilogue writes its LayerNorm output row-major
             if (r == 1)
                 WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
-                                     h->resid, nullptr, M, D, D, ACT_NONE, W16P(h, b + "attn.proj.weight")));
+                                     h->resid, nullptr, M, D, D, ACT_NONE, GX(W16P(h, b + "attn.proj.weight"))));
         }
         if (!n2_ready) {
             WM_TRY(launch_layernorm_block(h, s, m8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D, pk_lin1));
@@ -1341,7 +1498,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
                                 h->resid, h->resid, nullptr, nullptr, M, D, 4 * D, ACT_NONE));
         } else {
             WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.bias"), nullptr, 0, nullptr,
-                                 h->hid16, M, 4 * D, D, ACT_GELU, W16P(h, b + "mlp.lin1.weight"), xn_packed, pk_lin2));
+                                 h->hid16, M, 4 * D, D, ACT_GELU, GX(W16P(h, b + "mlp.lin1.weight"), xn_packed, pk_lin2)));
             WM_TRY(sat_check(h, s, WM_SAT_HID, h->hid16, (int64_t)M * 4 * D, P));
             // the fused kernel's operand type is also its LayerNorm output type: the next block's norm1 must want the same
             if (i + 1 < h->depth && block_prec(h, i + 1) == PB && !f8) {
@@ -1355,7 +1512,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
             }
             if (!xn_ready)
                 WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
-                                     h->resid, nullptr, M, D, 4 * D, ACT_NONE, W16P(h, b + "mlp.lin2.weight"), pk_lin2));
+                                     h->resid, nullptr, M, D, 4 * D, ACT_NONE, GX(W16P(h, b + "mlp.lin2.weight"), pk_lin2)));
         }
         WM_TRY(do_tap(h, s, i, B));
     }
@@ -1363,7 +1520,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     // ---- neck (image_encoder.py:105-121,136) ----
     WM_TRY(launch_simple(h, s, B * 31.5e6, cvt_f32_to_16_kernel<FP16>, dim3(grid_for((int64_t)M * D / 4)), dim3(256), (const float*)h->resid, (u16*)h->x16last, (int64_t)M * D / 4));
     WM_TRY(sat_check(h, s, WM_SAT_LAST, h->x16last, (int64_t)M * D, PS));
-    WM_TRY(launch_gemm16(h, s, PS, h->x16last, W16(h, e + "neck.0.weight"), nullptr, nullptr, 0, h->n1, nullptr, M, OUTC, D, ACT_NONE, W16P(h, e + "neck.0.weight")));
+    WM_TRY(launch_gemm16(h, s, PS, h->x16last, W16(h, e + "neck.0.weight"), nullptr, nullptr, 0, h->n1, nullptr, M, OUTC, D, ACT_NONE, GX(W16P(h, e + "neck.0.weight"))));
     WM_TRY(launch_layernorm(h, s, PS, h->n1, W32(h, e + "neck.1.weight"), W32(h, e + "neck.1.bias"), 1e-6f, nullptr, h->n1n16, M, OUTC));
     WM_TRY(launch_conv3x3_16(h, s, PS, h->n1n16, W16(h, e + "neck.2.weight"), h->n2, M, OUTC, OUTC));
     WM_TRY(launch_layernorm(h, s, PS, h->n2, W32(h, e + "neck.3.weight"), W32(h, e + "neck.3.bias"), 1e-6f, h->emb_nhwc, nullptr, M, OUTC));
@@ -1781,11 +1938,50 @@ extern "C" int wm_op_gemm16(const void* a_dev, const void* w_dev, const float* b
     if (layout && !gemm16_takes_v5(M, N, K))
         return fail("wm_op_gemm16: M=%d N=%d K=%d runs on a half-width kernel, which takes row-major operands only (wm_op_gemm16_takes_packed)", M, N, K);
     return launch_gemm16(nullptr, (hipStream_t)stream, precision, a_dev, (layout & WM_GEMM_W_PACKED) ? nullptr : w_dev, bias_dev, residual_dev, res_mod,
-                         out_f32_dev, out_16_dev, M, N, K, act, (layout & WM_GEMM_W_PACKED) ? w_dev : nullptr, (layout & WM_GEMM_A_PACKED) != 0,
-                         (layout & WM_GEMM_OUT_PACKED) != 0);
+                         out_f32_dev, out_16_dev, M, N, K, act, GX((layout & WM_GEMM_W_PACKED) ? w_dev : nullptr, (layout & WM_GEMM_A_PACKED) != 0,
+                                                                   (layout & WM_GEMM_OUT_PACKED) != 0));
 }
 
 extern "C" int wm_op_gemm16_takes_packed(int M, int N, int K) { return gemm16_takes_v5(M, N, K) ? 1 : 0; }
+
+extern "C" int wm_op_ln_stats16(const float* x_dev, float* stats_dev, void* x16_dev, int64_t rows, int C, int precision, void* stream) {
+    if (!x_dev || !stats_dev || !x16_dev) return fail("wm_op_ln_stats16: null buffer");
+    return launch_ln_stats16(nullptr, (hipStream_t)stream, precision, x_dev, stats_dev, x16_dev, rows, C);
+}
+
+extern "C" int wm_op_fold_weight16(const void* w16_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev, void* wf_dev,
+                                   float* c1_dev, float* c2_dev, int N, int K, int precision, void* stream) {
+    if (!w16_dev || !gamma_dev || !beta_dev || !wf_dev || !c1_dev || !c2_dev) return fail("wm_op_fold_weight16: null buffer");
+    if (N <= 0 || K <= 0 || N % 16 || K % 32) return fail("wm_op_fold_weight16: N=%d K=%d (N %% 16, K %% 32)", N, K);
+    if (precision == WM_PREC_FP16)
+        hipLaunchKernelGGL(fold_weight_kernel<FP16>, dim3(N), dim3(256), 0, (hipStream_t)stream, (const u16*)w16_dev, gamma_dev, beta_dev, bias_dev, (u16*)wf_dev, c1_dev, c2_dev, N, K);
+    else if (precision == WM_PREC_BF16)
+        hipLaunchKernelGGL(fold_weight_kernel<BF16>, dim3(N), dim3(256), 0, (hipStream_t)stream, (const u16*)w16_dev, gamma_dev, beta_dev, bias_dev, (u16*)wf_dev, c1_dev, c2_dev, N, K);
+    else return fail("wm_op_fold_weight16: precision %d", precision);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int wm_op_gemm16_folded(const void* x16_dev, const void* wf_dev, const float* c1_dev, const float* c2_dev, const float* stats_dev,
+                                   float eps, void* out_16_dev, int M, int N, int K, int act, int precision, void* stream) {
+    if (!x16_dev || !wf_dev || !c1_dev || !c2_dev || !stats_dev || !out_16_dev) return fail("wm_op_gemm16_folded: null buffer");
+    const int out_packed = (act & WM_GEMM_OUT_PACKED) != 0;
+    act &= ~WM_GEMM_OUT_PACKED;
+    if (!gemm16_takes_v5(M, N, K)) return fail("wm_op_gemm16_folded: M=%d N=%d K=%d is not served by the 256-row-tile kernel", M, N, K);
+    GemmExtra x = GX(wf_dev, 1, out_packed);
+    x.fold_stats = stats_dev; x.fold_c1 = c1_dev; x.fold_eps = eps;
+    return launch_gemm16(nullptr, (hipStream_t)stream, precision, x16_dev, nullptr, c2_dev, nullptr, 0, nullptr, out_16_dev, M, N, K, act, x);
+}
+
+extern "C" int wm_op_gemm16_stats(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev, float* out_f32_dev,
+                                  void* x16_dev, float* stats_dev, int M, int N, int K, int layout, int precision, void* stream) {
+    if (!a_dev || !w_dev || !residual_dev || !out_f32_dev || !x16_dev || !stats_dev) return fail("wm_op_gemm16_stats: null buffer");
+    if (!gemm16_takes_v5(M, N, K)) return fail("wm_op_gemm16_stats: M=%d N=%d K=%d is not served by the 256-row-tile kernel", M, N, K);
+    GemmExtra x = GX((layout & WM_GEMM_W_PACKED) ? w_dev : nullptr, (layout & WM_GEMM_A_PACKED) != 0, 0);
+    x.st_stats = stats_dev;
+    return launch_gemm16(nullptr, (hipStream_t)stream, precision, a_dev, (layout & WM_GEMM_W_PACKED) ? nullptr : w_dev, bias_dev, residual_dev, 0,
+                         out_f32_dev, x16_dev, M, N, K, ACT_NONE, x);
+}
 
 extern "C" int wm_op_pack16(const void* in_dev, void* out_dev, int64_t rows, int K, void* stream) {
     if (!in_dev || !out_dev || rows <= 0 || K <= 0 || rows % 16 || K % 32) return fail("wm_op_pack16: rows=%lld K=%d (rows %% 16, K %% 32)", (long long)rows, K);

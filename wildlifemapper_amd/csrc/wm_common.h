@@ -173,6 +173,15 @@ __device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float
     return fmaf((v - mean) * rstd, g, b);
 }
 
+// Element index of (row, col) of a [rows][C] 16-bit operand stored in LDS-image order (gemm16_v5.h "Operand layout"):
+// [rows / 16][C / 32][64 positions x 8 elements], position = (row % 16) * 4 + (chunk ^ ((-((row % 16) >> 2)) & 3)),
+// chunk = (col % 32) / 8.  rows % 16 == 0, C % 32 == 0.
+__device__ __forceinline__ int64_t lds_image_index(int64_t row, int col, int C) {
+    const int r = (int)(row & 15), cw = col & 31;
+    const int pos = r * 4 + ((cw >> 3) ^ ((0 - (r >> 2)) & 3));
+    return ((row >> 4) * (C >> 5) + (col >> 5)) * 512 + pos * 8 + (cw & 7);
+}
+
 // XCD-aware block remap (bijective for any grid size): blocks that share an XCD
 // (equal blockIdx % 8 under round-robin dispatch) get a contiguous range of
 // logical tile ids, so neighbouring tiles share operand panels in one L2.
