@@ -80,9 +80,13 @@ typedef struct wm_config {
  * produces each row's statistics and a 16-bit copy of the row, the following qkv / lin1 GEMM multiplies that copy with
  * gamma (.) W and applies rstd (acc - mean c1) + c2 in its epilogue (csrc/gemm16_v5.h "Folded LayerNorm") -- so the residual
  * stream is not re-read by a LayerNorm kernel.  Results differ from the unfolded path within the operand rounding (the
- * rounding points move), they do not depend on the batch size.  Also: env WM_LN_FOLD=1 (Python side).  Takes precedence over
- * WM_CFG_FUSE_LN. */
+ * rounding points move), they do not depend on the batch size.  Takes precedence over WM_CFG_FUSE_LN.  The Python drop-in
+ * sets it by default (WM_LN_FOLD=0 turns it off): +2.6 % tiles/s (ViT-H, B = 16), logits 2.3e-4 against 2.4e-4 unfolded.
+ * It covers the blocks whose operands are fp16.  bf16-operand blocks keep their LayerNorm kernel unless
+ * WM_CFG_FOLD_LN_BF16 is set as well: the folded weight gamma (.) W is rounded a second time, and with bf16's 8-bit mantissa
+ * that costs the logits 15-25 % more error (ViT-L 9.3e-4 -> 1.15e-3, ViT-H 8.2e-4 -> 9.5e-4), which bf16 cannot afford. */
 #define WM_CFG_FOLD_LN 2
+#define WM_CFG_FOLD_LN_BF16 4
 
 typedef struct wm_handle wm_handle;
 

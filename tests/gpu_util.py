@@ -89,6 +89,52 @@ def gemm16_ln(a16, w16, bias, residual, gamma, beta, eps, prec="bf16"):
     return x, o16
 
 
+def fold_bn(C):
+    return 320 if C % 320 == 0 else 256
+
+
+def ln_stats16(x, prec="fp16"):
+    """Folded LayerNorm, standalone producer: (stats [rows, C / BN, 2], x16 in LDS-image order)."""
+    code, dt = PRECS[prec]
+    rows, Cc = x.shape
+    stats = torch.empty((rows, Cc // fold_bn(Cc), 2), device=x.device, dtype=torch.float32)
+    x16 = torch.empty((rows, Cc), device=x.device, dtype=dt)
+    N.check(N.lib().wm_op_ln_stats16(N.ptr(x), N.ptr(stats), N.ptr(x16), rows, Cc, code, sp()))
+    return stats, x16
+
+
+def fold_weight16(w16, gamma, beta, bias, prec="fp16"):
+    code, dt = PRECS[prec]
+    Nn, K = w16.shape
+    wf = torch.empty_like(w16)
+    c1 = torch.empty(Nn, device=w16.device, dtype=torch.float32)
+    c2 = torch.empty(Nn, device=w16.device, dtype=torch.float32)
+    N.check(N.lib().wm_op_fold_weight16(N.ptr(w16), N.ptr(gamma), N.ptr(beta), N.ptr(bias), N.ptr(wf), N.ptr(c1), N.ptr(c2), Nn, K, code, sp()))
+    return wf, c1, c2
+
+
+def gemm16_folded(x16, wf, c1, c2, stats, eps, act=0, prec="fp16", out_packed=False):
+    code, dt = PRECS[prec]
+    M, K = x16.shape
+    Nn = wf.shape[0]
+    out = torch.empty((M, Nn), device=x16.device, dtype=dt)
+    N.check(N.lib().wm_op_gemm16_folded(N.ptr(x16), N.ptr(wf), N.ptr(c1), N.ptr(c2), N.ptr(stats), eps, N.ptr(out), M, Nn, K,
+                                        act | (N.GEMM_OUT_PACKED if out_packed else 0), code, sp()))
+    return out
+
+
+def gemm16_stats(a16, w16, bias, residual, prec="fp16", layout=0):
+    """Folded LayerNorm, producing GEMM: (out32 = residual + a w^T + bias, x16 copy, stats)."""
+    code, dt = PRECS[prec]
+    M, K = a16.shape
+    Nn = w16.shape[0]
+    out = residual.clone()
+    x16 = torch.empty((M, Nn), device=a16.device, dtype=dt)
+    stats = torch.empty((M, Nn // fold_bn(Nn), 2), device=a16.device, dtype=torch.float32)
+    N.check(N.lib().wm_op_gemm16_stats(N.ptr(a16), N.ptr(w16), N.ptr(bias), N.ptr(out), N.ptr(out), N.ptr(x16), N.ptr(stats), M, Nn, K, layout, code, sp()))
+    return out, x16, stats
+
+
 def gemm32(a, w, bias=None, residual=None, act=0):
     M, K = a.shape
     Nn = w.shape[0]

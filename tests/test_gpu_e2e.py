@@ -284,16 +284,20 @@ def test_fused_layernorm_option_is_bit_identical():
     m, _ = _model("vit_b", "bf16")
     x = torch.from_numpy(synth.make_batch(20, 4)).to(G.dev())          # 4 tiles: 64 x 3 = 192 workgroups -> fusable
     hub = m._hub
-    base = m(NestedTensor(x, None), None)
-    base1 = m(NestedTensor(x[2:3].contiguous(), None), None)
-    hub.fuse_ln = True
-    hub.close()                                                        # next forward re-creates the handle with the flag
+    fold_was = hub.fold_ln
+    hub.fold_ln = False                                                # the folded LayerNorm (default) takes precedence over this option
+    hub.close()
     try:
+        base = m(NestedTensor(x, None), None)
+        base1 = m(NestedTensor(x[2:3].contiguous(), None), None)
+        hub.fuse_ln = True
+        hub.close()                                                    # next forward re-creates the handle with the flag
         fused = m(NestedTensor(x, None), None)
         fused1 = m(NestedTensor(x[2:3].contiguous(), None), None)      # 1 tile: too few workgroups, separate kernels
         st = hub.profile_read() if hasattr(hub, "profile_read") else None   # raises if a fused launch timed out
     finally:
         hub.fuse_ln = False
+        hub.fold_ln = fold_was
         hub.close()
     assert torch.equal(fused["pred_logits"], base["pred_logits"]) and torch.equal(fused["pred_boxes"], base["pred_boxes"])
     assert torch.equal(fused1["pred_logits"], base1["pred_logits"])
@@ -418,9 +422,12 @@ def test_vit_h_batches_golden_tile_and_bit_identity(prec, golden_dir):
     depth = synth.MODEL_DIMS["vit_h"].depth
     for B in (16, 4):
         v = variants[B]
-        assert v.get("v5_320_res", 0) >= 2 * depth and v.get("v5_320", 0) >= 2 * depth, v     # proj + lin2, qkv + lin1 of every block
+        # proj + lin2 of every block: with the folded LayerNorm (default) the statistics-producing instance, except the last lin2
+        # (fp16-operand blocks; bf16 mode keeps the LayerNorm kernel and the plain residual instance)
+        assert v.get("v5_320_foldp", 0) + v.get("v5_320_res", 0) >= 2 * depth and v.get("v5_320_foldp", 0) >= (2 * depth - 1 if prec == "fp16" else 0), v
+        assert v.get("v5_320", 0) >= 2 * depth, v                      # qkv + lin1 of every block
         assert "v2_160" not in v and "v1_128" not in v, v
-    assert variants[1].get("v2_160", 0) >= 2 * depth and variants[1].get("v5_320_res", 0) == 0, variants[1]
+    assert variants[1].get("v2_160", 0) >= 2 * depth and variants[1].get("v5_320_res", 0) == 0 and variants[1].get("v5_320_foldp", 0) == 0, variants[1]
     for B in (16, 5, 4, 1):
         lg = outs[B]["pred_logits"][:1].numpy()
         lerr = np.linalg.norm(lg - fx["pred_logits"]) / np.linalg.norm(fx["pred_logits"])
@@ -667,6 +674,67 @@ def test_vit_h_outlier_weight_profile_vs_reference_golden(golden_dir):
             assert prec != "fp16" or all(same), same
     finally:
         m.load_state_dict(base, strict=True)
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_vit_h_folded_layernorm_vs_reference_golden(prec, golden_dir):
+    """WM_CFG_FOLD_LN: the blocks' LayerNorms folded into the GEMMs around them (statistics from the residual GEMM's epilogue,
+    normalisation in the qkv / lin1 epilogue).  Against the reference fixtures: tile 0 (with nine block taps' worth of logits
+    checked through the final outputs), tiles 1..4 and the outlier weight profile; per tile the logits bar of the precision
+    and, in fp16 mode, identical NMS lists.  And batch invariance: tile 0 alone (B = 1: statistics from the standalone kernel,
+    half-width residual GEMMs), in a batch of 4 and in a batch of 16 (statistics from the producing GEMMs) gives the same bits."""
+    from wildlifemapper_amd import _native as Nn
+    m, _ = _model("vit_h", prec)
+    hub = m._hub
+    fold_was = hub.fold_ln
+    hub.close(); hub.fold_ln = "all"                      # bf16-operand blocks fold only on request (WM_CFG_FOLD_LN_BF16)
+    base = None
+    try:
+        outs = {}
+        for B in (1, 4, 16):
+            x = torch.from_numpy(synth.make_batch(0, B)).to(G.dev())
+            with torch.no_grad():
+                m.detect(x, torch.tensor([[1024, 1024]] * B))
+                Nn.gemm_variant_counts(reset=True)
+                outs[B] = {k: v.cpu() for k, v in m.detect(x, torch.tensor([[1024, 1024]] * B)).items()}
+            var = {k: v for k, v in Nn.gemm_variant_counts().items() if v}
+            if B >= 4:
+                # producers: 32 x proj + 31 x lin2 (the last block's has no consumer) + the stem's proj_back where its fp16 operand
+                # type is also block 0's (fp16 mode)
+                assert var.get("v5_320_foldp", 0) == (64 if prec == "fp16" else 63), var
+            else:
+                assert var.get("v5_320_foldp", 0) == 0, var
+        for B in (4, 16):
+            assert torch.equal(outs[B]["pred_logits"][0], outs[1]["pred_logits"][0]), B
+            assert torch.equal(outs[B]["pred_boxes"][0], outs[1]["pred_boxes"][0]), B
+        for fixture in ("e2e_vit_h.npz", "e2e_vit_h_tiles1to4.npz"):
+            fx = np.load(os.path.join(golden_dir, fixture))
+            n, first = int(fx["n_tiles"]), int(fx["first_tile"])
+            lg = outs[16]["pred_logits"][first:first + n].numpy()
+            rec = split_records(outs[16]["records"][first:first + n])
+            errs = [float(np.linalg.norm(lg[t] - fx["pred_logits"][t]) / np.linalg.norm(fx["pred_logits"][t])) for t in range(n)]
+            same = [_nms_positions(rec, t) == fx[f"pp{t}_nms_index"].tolist() for t in range(n)]
+            print(f"[vit_h/{prec}/folded LN] {fixture}: logits per tile " + " ".join(f"{e:.2e}" for e in errs) + f" NMS identical: {same}")
+            assert max(errs) < LOGIT_TOL[prec], errs
+            assert all(same), same
+        # the outlier weight profile through the folded path
+        fx = np.load(os.path.join(golden_dir, "e2e_vit_h_outlier.npz"))
+        base = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_state_dict("vit_h", 0, profile="outlier").items()}, strict=True)
+        x = torch.from_numpy(synth.make_batch(0, 2)).to(G.dev())
+        with torch.no_grad():
+            out = m.detect(x, torch.tensor([[1024, 1024]] * 2))
+        lg = out["pred_logits"].cpu().numpy()
+        rec = split_records(out["records"].cpu())
+        errs = [float(np.linalg.norm(lg[t] - fx["pred_logits"][t]) / np.linalg.norm(fx["pred_logits"][t])) for t in range(2)]
+        same = [_nms_positions(rec, t) == fx[f"pp{t}_nms_index"].tolist() for t in range(2)]
+        print(f"[vit_h/{prec}/folded LN/outlier profile] logits per tile " + " ".join(f"{e:.2e}" for e in errs) + f" NMS identical: {same}")
+        assert max(errs) < {"fp16": LOGIT_TOL["fp16"], "bf16": 5e-3}[prec], errs
+        assert prec != "fp16" or all(same), same
+    finally:
+        if base is not None:
+            m.load_state_dict(base, strict=True)
+        hub.close(); hub.fold_ln = fold_was
 
 
 def test_input_pipeline_resize_bit_exact_vs_pil(golden_dir):

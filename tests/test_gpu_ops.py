@@ -270,6 +270,93 @@ def test_layernorm_packed_output(prec, C):
     assert torch.equal(packed, G.pack16(plain))
 
 
+# ---------------------------------------------------------------------------
+# Folded LayerNorm (WM_CFG_FOLD_LN): statistics in the producing GEMM, normalisation in the consuming GEMM
+# ---------------------------------------------------------------------------
+def _outlier_rows(M, C, dev):
+    """Residual-stream-like rows: unit bulk, a per-row offset, two massive channels (~200x) as the outlier weight profile makes."""
+    x = torch.randn(M, C, device=dev) * (0.7 + torch.rand(M, 1, device=dev)) + 0.2 * torch.randn(M, 1, device=dev)
+    x[:, 101] += 190.0
+    x[:, 678 % C] -= 240.0
+    return x
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("C", [1280, 1024, 768])
+def test_ln_stats16_partials_and_copy(prec, C):
+    dev = G.dev()
+    x = _outlier_rows(4096, C, dev)
+    stats, x16 = G.ln_stats16(x, prec)
+    bn = G.fold_bn(C)
+    xt = x.double().view(4096, C // bn, bn)
+    mean = xt.mean(-1)
+    m2 = ((xt - mean[..., None]) ** 2).sum(-1)
+    assert (stats[..., 0].double() - mean).abs().max().item() < 1e-5 * max(1.0, mean.abs().max().item())
+    assert ((stats[..., 1].double() - m2).abs() / m2).max().item() < 1e-5
+    assert torch.equal(G.unpack16_torch(x16), G.to16(x, prec))
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_fold_weight16(prec):
+    dev = G.dev()
+    Nn, K = 768, 1280
+    w = G.to16(torch.randn(Nn, K, device=dev) / math.sqrt(K), prec)
+    g, b, bias = 1 + 0.3 * torch.randn(K, device=dev), 0.2 * torch.randn(K, device=dev), torch.randn(Nn, device=dev)
+    g[5] = 50.0
+    wf, c1, c2 = G.fold_weight16(w, g, b, bias, prec)
+    want_wf = G.to16(w.float() * g, prec)
+    assert torch.equal(G.unpack16_torch(wf), want_wf)
+    assert (c1.double() - want_wf.double().sum(1)).abs().max().item() < 1e-4
+    assert (c2.double() - ((w.double() * b.double()).sum(1) + bias.double())).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K,act", [(16384, 3840, 1280, 0), (16384, 5120, 1280, 1), (12288, 3072, 768, 1), (16384, 3072, 1024, 0)])
+def test_gemm16_folded_equals_layernorm_then_gemm(M, N, K, act, prec):
+    """LN(x) W^T + b computed as rstd (x16 (gamma W)^T - mean c1) + c2 in the GEMM epilogue, against fp32 torch, and no worse
+    than the classic route (LayerNorm kernel -> 16-bit -> GEMM) on rows with massive channels and a per-row offset."""
+    dev = G.dev()
+    x = _outlier_rows(M, K, dev)
+    w = G.to16(torch.randn(N, K, device=dev) / math.sqrt(K), prec)
+    g, b, bias = 1 + 0.2 * torch.randn(K, device=dev), 0.1 * torch.randn(K, device=dev), torch.randn(N, device=dev)
+    g[17], g[300] = 50.0, -30.0
+    want = torch.nn.functional.layer_norm(x, (K,), g, b, 1e-6) @ w.float().t() + bias
+    want = O.gelu_erf(want) if act == 1 else want
+    stats, x16 = G.ln_stats16(x, prec)
+    wf, c1, c2 = G.fold_weight16(w, g, b, bias, prec)
+    got = G.gemm16_folded(x16, wf, c1, c2, stats, 1e-6, act, prec)
+    e_fold = G.rel_l2(got.float(), want)
+    _, xn16 = G.layernorm(x, g, b, 1e-6, prec, want32=False, want16=True)
+    _, classic = G.gemm16(xn16, w, bias, None, 0, act, prec, want32=False, want16=True)
+    e_classic = G.rel_l2(classic.float(), want)
+    print(f"[fold {prec} M={M} N={N} K={K} act={act}] folded {e_fold:.2e}  classic {e_classic:.2e}")
+    assert e_fold < 2.5 * OUT16_TOL[prec] and e_fold < 2.0 * e_classic + 1e-4
+    got_p = G.gemm16_folded(x16, wf, c1, c2, stats, 1e-6, act, prec, out_packed=True)
+    assert torch.equal(G.unpack16_torch(got_p), got)
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(16384, 1280, 1280), (16384, 1280, 5120), (65536, 1280, 1280), (16384, 1024, 1024), (12288, 768, 3072)])
+def test_gemm16_stats_producer_is_the_residual_gemm_plus_the_standalone_statistics(M, N, K, prec):
+    """The producing GEMM (FOLDP instance) writes the same fp32 rows as the plain residual GEMM, and the statistics / 16-bit
+    copy it adds are bit-identical to what the standalone kernel computes from those rows: a tile's folded LayerNorm does not
+    depend on which of the two produced them (i.e. on the batch size)."""
+    dev = G.dev()
+    a = G.to16(torch.randn(M, K, device=dev), prec)
+    w = G.to16(torch.randn(N, K, device=dev) / math.sqrt(K), prec)
+    bias = torch.randn(N, device=dev)
+    r = _outlier_rows(M, N, dev)
+    base32, _ = G.gemm16(a, w, bias, r, 0, 0, prec, want32=True, want16=False)
+    (out32, x16, stats), var = _variants_run(lambda: G.gemm16_stats(a, w, bias, r, prec))
+    assert var == {("v5_320_foldp" if N % 320 == 0 else "v5_256_foldp"): 1}
+    assert torch.equal(out32, base32)
+    st2, x2 = G.ln_stats16(out32, prec)
+    assert torch.equal(stats, st2) and torch.equal(x16, x2)
+    from wildlifemapper_amd import _native as Nn
+    o2, x3, st3 = G.gemm16_stats(G.pack16(a), G.pack16(w), bias, r, prec, layout=Nn.GEMM_W_PACKED | Nn.GEMM_A_PACKED)
+    assert torch.equal(o2, base32) and torch.equal(x3, x16) and torch.equal(st3, stats)
+
+
 def test_gemm16_kernels_agree_bitwise():
     """A tile's result must not depend on which GEMM kernel its batch size selects (batch-invariant
     bit for bit): the same rows through the half-width kernel (M = 4096) and through the staggered 256 x 320 kernel

@@ -230,7 +230,7 @@ struct wm_handle {
     std::map<std::string, uint16_t*> wfold;
     std::map<std::string, float*> fold_c1, fold_c2;
     float* fold_stats = nullptr;
-    bool fold = false;
+    bool fold = false, fold_bf16 = false;   // WM_CFG_FOLD_LN: fp16-operand blocks; WM_CFG_FOLD_LN_BF16: bf16-operand blocks too
     std::map<std::string, uint16_t*> w16p;  // the same weights in LDS-image order (gemm16_v5.h "Operand layout"), for the 256-row-tile kernels
     std::map<std::string, uint8_t*> w8;     // WM_PREC_FP8: e4m3 weights of the blocks' GEMMs; their per-channel scales live in w32[name + ".wscale"]
     uint8_t* ao8 = nullptr;                 // attention output as e4m3 (A operand of proj)
@@ -1052,7 +1052,8 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     h->fp8_bf16_tail = getenv("WM_FP8_BF16_TAIL") ? atoi(getenv("WM_FP8_BF16_TAIL")) : 0;
     h->fp8_bf16_head = getenv("WM_FP8_BF16_HEAD") ? atoi(getenv("WM_FP8_BF16_HEAD")) : 0;
     h->row_major = getenv("WM_ROW_MAJOR_OPERANDS") && atoi(getenv("WM_ROW_MAJOR_OPERANDS")) != 0;
-    h->fold = (cfg->flags & WM_CFG_FOLD_LN) != 0 && !h->row_major;
+    h->fold = (cfg->flags & (WM_CFG_FOLD_LN | WM_CFG_FOLD_LN_BF16)) != 0 && !h->row_major;
+    h->fold_bf16 = (cfg->flags & WM_CFG_FOLD_LN_BF16) != 0;
     h->fp8_gemms = cfg->fp8_gemms ? (cfg->fp8_gemms & WM_FP8_ALL) : (getenv("WM_FP8_GEMMS") ? (atoi(getenv("WM_FP8_GEMMS")) & WM_FP8_ALL) : WM_FP8_ALL);
     if (cfg->precision == WM_PREC_FP8 && h->fp8_gemms == 0) { delete h; return fail("wm_create: fp8_gemms selects no GEMM"); }
     h->D = cfg->embed_dim; h->depth = cfg->depth; h->heads = cfg->num_heads; h->hd = hd;
@@ -1378,7 +1379,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     auto fold_block = [&](int i) {
         const int pb = block_prec(h, i);
         const std::string b = e + "blocks." + std::to_string(i) + ".";
-        return h->fold && pb != WM_PREC_FP8 && gemm16_takes_v5(M, 3 * D, D) && gemm16_takes_v5(M, 4 * D, D) &&
+        return h->fold && (pb == WM_PREC_FP16 || (pb == WM_PREC_BF16 && h->fold_bf16)) && gemm16_takes_v5(M, 3 * D, D) && gemm16_takes_v5(M, 4 * D, D) &&
                h->wfold.count(b + "attn.qkv.weight") && h->wfold.count(b + "mlp.lin1.weight");
     };
     int raw_prec = -1;
