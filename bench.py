@@ -231,12 +231,20 @@ def cpu_baseline(model_type: str, sd, model, device, x_batch, ts_batch, first_ti
     return base, parity
 
 
-def time_config(model, x, ts, precision: str, workload: str, batch: int, steps: int, warmup: int, device, fp8_gemms: int = 0) -> dict:
+def time_config(model, x, ts, precision: str, workload: str, batch: int, steps: int, warmup: int, device, fp8_gemms: int = 0,
+                fold_ln=None, fp8_bf16_head_tail=(0, 0), gemm_rate: bool = False) -> dict:
     """A short timed run of another BASELINE.json configuration in this same process (same model object, weights re-packed
-    for the precision): W warm-up steps, K timed steps between device synchronisations, inputs resident."""
+    for the precision): W warm-up steps, K timed steps between device synchronisations, inputs resident.  gemm_rate: one more
+    pass of the K steps with per-kernel HIP events for the GEMM class's TFLOP/s."""
     hub = model._hub
     hub.set_precision(precision)
     hub.set_fp8_gemms(fp8_gemms)
+    if fold_ln is not None and fold_ln != hub.fold_ln:
+        hub.fold_ln = fold_ln
+        hub.close()
+    os.environ["WM_FP8_BF16_HEAD"], os.environ["WM_FP8_BF16_TAIL"] = str(fp8_bf16_head_tail[0]), str(fp8_bf16_head_tail[1])
+    if precision == "fp8":
+        hub.close()                                   # the head / tail dials are read when the handle is created
     xb, tb = x[:batch].contiguous(), ts[:batch].contiguous()
     hfc = model.fft(xb) if workload == "encoder" else None
 
@@ -256,8 +264,22 @@ def time_config(model, x, ts, precision: str, workload: str, batch: int, steps: 
         dt = time.perf_counter() - t0
     r = {"precision": precision, "workload": workload, "batch": batch, "steps": steps, "warmup": warmup,
          "tiles_per_s": round(batch * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3)}
+    if gemm_rate:
+        hub.profile_enable(True)
+        hub.profile_reset()
+        with torch.no_grad():
+            for _ in range(steps):
+                step()
+        torch.cuda.synchronize(device)
+        st = hub.profile_read()
+        hub.profile_enable(False)
+        g = st["gemm16"]
+        r["gemm_class_tflops"] = round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 1) if g["ms"] > 0 else None
+        r["gemm_class_frac_of_peak"] = round(r["gemm_class_tflops"] / PEAK_TFLOPS[precision], 4) if r["gemm_class_tflops"] else None
+        r["kernel_classes_ms_per_step"] = {k: round(v["ms"] / steps, 3) for k, v in st.items()}
     if precision == "fp8":
         r["fp8_gemms"] = {0: "all (qkv, proj, lin1, lin2)", 4: "lin1 + lin2", 5: "qkv + lin1 + lin2", 6: "proj + lin1 + lin2", 7: "all"}.get(fp8_gemms, str(fp8_gemms))
+        r["fp8_bf16_head_tail_blocks"] = list(fp8_bf16_head_tail)
     if workload == "full":
         par = parity_vs_reference_fixtures("vit_h", out, 0)
         if par:
@@ -388,6 +410,11 @@ def main() -> None:
                 traffic = None
             roofline = {"bound": "mfma", "kernel": ("gemm8_kernel (fp8 block-scaled MFMA, the blocks' 4 projections) + the stem / neck fp16 GEMMs" if a.precision == "fp8"
                                                     else "gemm16v5_kernel<T,320|256,3> (all 16-bit MFMA GEMM launches)"),
+                        "folded_layernorm": bool(hub.fold_ln) and a.precision == "fp16" or hub.fold_ln == "all" and a.precision == "bf16",
+                        "note": ("with the folded LayerNorm (default, fp16 operands) the GEMM launches also carry the blocks' LayerNorms -- row statistics and a "
+                                 "16-bit copy of the stream in the residual GEMMs' epilogues, the normalisation in the qkv / lin1 epilogues -- so their "
+                                 "time rises by ~3 ms per step while the LayerNorm class drops by ~6 ms: tiles/s up 2.6 %, this fraction down ~0.02; "
+                                 "other_configs holds the same step with the LayerNorm as its own kernel") if a.precision == "fp16" and hub.fold_ln else None,
                         "achieved": round(achieved, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                         "traffic_note": f"HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/{traffic_src} (tools/pmc_summarize.py)" if traffic_src else None,
@@ -435,16 +462,26 @@ def main() -> None:
         # fp8 mix that keeps the reference's detections.  Short runs (5 steps): indicative, the headline is `value`.
         if world == 1 and a.model == "vit_h" and not a.no_other_configs and B >= 4:
             others = []
+            fold_default = hub.fold_ln
             try:
                 others.append(dict(time_config(model, x, ts, "bf16", "encoder", 4, 5, 2, device), config="BASELINE.json configs[1]: ViT-H encoder bf16, batch=4"))
                 if B >= 16:
-                    others.append(dict(time_config(model, x, ts, "bf16", "full", 16, 5, 2, device), config="configs[2] with bf16 operands"))
-                    others.append(dict(time_config(model, x, ts, "fp8", "full", 16, 5, 2, device), config="BASELINE.json configs[4]: fp8, all four GEMMs of every block"))
-                    others.append(dict(time_config(model, x, ts, "fp8", "full", 16, 5, 2, device, fp8_gemms=N_.FP8_MLP),
-                                       config="configs[4] variant: fp8 MLP pair only (qkv / proj / attention bf16)"))
+                    others.append(dict(time_config(model, x, ts, "bf16", "full", 16, 5, 2, device, gemm_rate=True), config="configs[2] with bf16 operands (LayerNorm as its own kernel)"))
+                    others.append(dict(time_config(model, x, ts, "fp16", "full", 16, 5, 2, device, fold_ln=False, gemm_rate=True),
+                                       config="configs[2], fp16 operands, LayerNorm as its own kernel (WM_LN_FOLD=0): the GEMM class without the folded "
+                                              "LayerNorm's statistics / 16-bit-copy / normalisation work in its epilogues"))
+                    others.append(dict(time_config(model, x, ts, "fp8", "full", 16, 5, 2, device, fold_ln=fold_default, gemm_rate=True),
+                                       config="BASELINE.json configs[4]: fp8, all four GEMMs of every block"))
+                    others.append(dict(time_config(model, x, ts, "fp8", "full", 16, 5, 2, device, fp8_gemms=N_.FP8_MLP, fp8_bf16_head_tail=(8, 8)),
+                                       config="configs[4] variant closest to the reference's detections in the sweep (profiles/r3_fp8_gemm_mask_sweep.txt): fp8 MLP "
+                                              "pair only, first / last 8 blocks bf16"))
             finally:
+                os.environ["WM_FP8_BF16_HEAD"], os.environ["WM_FP8_BF16_TAIL"] = "0", "0"
                 hub.set_fp8_gemms(0)
                 hub.set_precision(a.precision)
+                if hub.fold_ln != fold_default:
+                    hub.fold_ln = fold_default
+                    hub.close()
             line["other_configs"] = others
         if not a.no_cpu_baseline and world == 1 and a.workload == "full":
             line["cpu_baseline"], line["map_vs_cpu_ref"] = cpu_baseline(a.model, sd, model, device, x, ts, first, {k: v.cpu() for k, v in out_batch.items()})
