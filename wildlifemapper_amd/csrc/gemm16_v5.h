@@ -60,8 +60,11 @@ namespace wm {
 // residual in 16 bits: its rounding error relative to LN's input scale is what rounding the normalised value costs, as long
 // as a row's mean is not large against its spread (it is not: per-token means of the stream are O(0.1 sigma), outlier profile
 // included); fp16's range holds for |x| < 65504 (the saturation census watches this buffer).
-template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false, bool FOLDP = false>
+// (FOLDC, the consumer, is an instance of its own: compiled into the plain instance its extra epilogue state cost that kernel
+// 114 spilled registers.)
+template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false, bool FOLDP = false, bool FOLDC = false>
 __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
+    static_assert(!(FOLDC && (LNF || FOLDP || DBG)), "the folded-LayerNorm consumer is the plain 16-bit-output kernel");
     using C = G3<BN, 4>;
     constexpr int AHEAD = NSLOT - 1;                       // K-steps of DMA in flight
     // timing experiments of tools/gemm_bench.py (--act 256 / 512 / 1024): compiled in only with -DWM_GEMM_TIMING_BITS=1
@@ -203,13 +206,21 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (p.residual) res_dma(0);
-    constexpr int FOLD_RAW = LDS_TOTAL - RES_BYTES, FOLD_MR = FOLD_RAW + 8192;      // landing buffer 0 is idle without a residual
-    if constexpr (!LNF && !FOLDP) {
-        if (p.fold_stats) {
-            // the row block's partial statistics: 256 rows x fold_ntile x (mean, M2), contiguous; one DMA piece per wave
-            if (wave * 1024 < 256 * p.fold_ntile * 8)
-                __builtin_amdgcn_global_load_lds((const char*)(p.fold_stats + (size_t)m0 * p.fold_ntile * 2) + wave * 1024 + lane * 16,
-                                                 WM_LDS_PTR(smem + FOLD_RAW + wave * 1024), 16, 0, 0);
+    // landing buffer 0 is idle without a residual: raw partials (8 KiB), (mean, rstd) per row (2 KiB), c1 | c2 of the tile's columns
+    constexpr int FOLD_RAW = LDS_TOTAL - RES_BYTES, FOLD_MR = FOLD_RAW + 8192, FOLD_C = FOLD_MR + 2048;
+    static_assert(FOLD_C + 2 * BN * 4 <= LDS_TOTAL, "fold LDS map");
+    if constexpr (FOLDC) {
+        // the row block's partial statistics: 256 rows x fold_ntile x (mean, M2), contiguous; one DMA piece per wave
+        if (wave * 1024 < 256 * p.fold_ntile * 8)
+            __builtin_amdgcn_global_load_lds((const char*)(p.fold_stats + (size_t)m0 * p.fold_ntile * 2) + wave * 1024 + lane * 16,
+                                             WM_LDS_PTR(smem + FOLD_RAW + wave * 1024), 16, 0, 0);
+        // c1 and c2 (= the bias argument) of this tile's BN columns: 256-byte pieces (4 B per lane: exact, no over-read), into LDS
+        // rather than 40 registers per lane -- the epilogue keeps the 160 accumulators live and reads them per column fragment
+        constexpr int PC = BN * 4 / 256;
+#pragma unroll
+        for (int pi = wave; pi < 2 * PC; pi += C::WAVES) {
+            const float* src = (pi < PC ? p.fold_c1 + n0 + pi * 64 : p.bias + n0 + (pi - PC) * 64) + lane;
+            __builtin_amdgcn_global_load_lds(src, WM_LDS_PTR(smem + FOLD_C + (pi < PC ? pi * 256 : BN * 4 + (pi - PC) * 256)), 4, 0, 0);
         }
     }
 
@@ -275,15 +286,14 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     // along the row, and the residual is read the same way.
     const int act = p.act & 0xff;
     const int tid_e = tid, fr_e = fr, fq_e = fq;
-    f32x4 bias_v[C::NT];
+    f32x4 bias_v[FOLDC ? 1 : C::NT];
+    if constexpr (!FOLDC) {
 #pragma unroll
-    for (int ni = 0; ni < C::NT; ++ni)
-        bias_v[ni] = p.bias ? *(const f32x4*)(p.bias + n0 + wc * C::WCOLS + ni * 16 + fq_e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 c1_v[C::NT];
-    if constexpr (!LNF && !FOLDP) {
-        if (p.fold_stats) {
-#pragma unroll
-            for (int ni = 0; ni < C::NT; ++ni) c1_v[ni] = *(const f32x4*)(p.fold_c1 + n0 + wc * C::WCOLS + ni * 16 + fq_e * 4);
+        for (int ni = 0; ni < C::NT; ++ni)
+            bias_v[ni] = p.bias ? *(const f32x4*)(p.bias + n0 + wc * C::WCOLS + ni * 16 + fq_e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (FOLDC) {
+        {
             if (tid < C::BM) {                              // one row per thread: Chan combination of its column-tile partials
                 const float2* raw = (const float2*)(smem + FOLD_RAW) + tid * p.fold_ntile;
                 float mk[8], qk[8];
@@ -301,27 +311,14 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): this wave's fragment reads are back
     barrier();                                              // every wave is done with the ring
     if constexpr (DBG) we[0] = wall_clock64();
-    float2 row_mr[C::MT];                                   // fold: (mean, rstd) of this lane's row of every row fragment
-    if constexpr (!LNF && !FOLDP) {
-        if (p.fold_stats) {
-#pragma unroll
-            for (int mi = 0; mi < C::MT; ++mi) row_mr[mi] = *(const float2*)(smem + FOLD_MR + (wr * 128 + mi * 16 + fr_e) * 8);
-        }                                                   // (the epilogue's staging never touches FOLD_RAW / FOLD_MR)
-    }
+    // (the epilogue's staging never touches FOLD_RAW / FOLD_MR / FOLD_C)
     // one straight-line instance per activation (a per-fragment runtime branch costs more than the stores)
     auto epilogue = [&](auto act_tag, auto fold_tag) {
     constexpr int ACT = decltype(act_tag)::value;
-    constexpr bool FOLD = decltype(fold_tag)::value;
+    constexpr bool FOLD = decltype(fold_tag)::value && FOLDC;
     const int tid = tid_e, fr = fr_e, fq = fq_e;           // shadow the kernel-scope values (see tid_e)
-    auto finish = [&](f32x4 v, int ni, int mi = 0) {
-        if constexpr (FOLD) {
-            // LayerNorm folded into this GEMM: rstd (acc - mean c1) + c2, c2 arriving as the bias
-            const float mean = row_mr[mi].x, rstd = row_mr[mi].y;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaf(fmaf(-mean, c1_v[ni][j], v[j]), rstd, bias_v[ni][j]);
-        } else {
-            v += bias_v[ni];
-        }
+    auto finish = [&](f32x4 v, int ni) {
+        if constexpr (!FOLD) v += bias_v[ni];              // FOLD: the caller has applied rstd (acc - mean c1) + c2
         if constexpr (ACT == ACT_GELU) {
             v = gelu_erf_fast4(v);
         } else if constexpr (ACT == ACT_RELU) {
@@ -485,16 +482,40 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         auto epi_sync = [&]() { __syncthreads(); };
 #pragma unroll
         for (int q = 0; q < C::MT / MTP; ++q) {
+            if constexpr (FOLD) {
+                // LayerNorm folded into this GEMM: rstd (acc - mean c1) + c2.  (mean, rstd) of the pass's MTP rows and, per column
+                // fragment, c1 / c2 are read from LDS once and reused (28 reads per lane and tile instead of 120)
+                float2 mr[MTP];
+#pragma unroll
+                for (int mm = 0; mm < MTP; ++mm) mr[mm] = *(const float2*)(smem + FOLD_MR + (wr * 128 + (q * MTP + mm) * 16 + fr) * 8);
+#pragma unroll
+                for (int ni = 0; ni < C::NT; ++ni) {
+                    const f32x4 c1 = *(const f32x4*)(smem + FOLD_C + (wc * C::WCOLS + ni * 16 + fq * 4) * 4);
+                    const f32x4 c2 = *(const f32x4*)(smem + FOLD_C + BN * 4 + (wc * C::WCOLS + ni * 16 + fq * 4) * 4);
+#pragma unroll
+                    for (int mm = 0; mm < MTP; ++mm) {
+                        f32x4 v = acc[q * MTP + mm][ni];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaf(fmaf(-mr[mm].x, c1[j], v[j]), mr[mm].y, c2[j]);
+                        v = finish(v, ni);
+                        typename T::vec4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+                        *(typename T::vec4*)(smem + EPI_BASE + (wr * MTP * 16 + mm * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 2) = o;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int mm = 0; mm < MTP; ++mm)
 #pragma unroll
                 for (int ni = 0; ni < C::NT; ++ni) {
-                    const f32x4 v = finish(acc[q * MTP + mm][ni], ni, q * MTP + mm);
+                    const f32x4 v = finish(acc[q * MTP + mm][ni], ni);
                     typename T::vec4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
                     *(typename T::vec4*)(smem + EPI_BASE + (wr * MTP * 16 + mm * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 2) = o;
                 }
+            }
             epi_sync();
             if constexpr (DBG) { if (q < 2) we[1 + 2 * q] = wall_clock64(); }
             if (p.out_packed) {
@@ -592,11 +613,11 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     };
     if constexpr (LNF || FOLDP) {
         epilogue(std::integral_constant<int, ACT_NONE>{}, std::false_type{});
+    } else if constexpr (FOLDC) {                            // folded LayerNorm: the 16-bit-output GEMMs qkv (no activation) and lin1 (GELU)
+        if (act == ACT_GELU) epilogue(std::integral_constant<int, ACT_GELU>{}, std::true_type{});
+        else epilogue(std::integral_constant<int, ACT_NONE>{}, std::true_type{});
     } else {
-        if (p.fold_stats) {                                  // folded LayerNorm: the 16-bit-output GEMMs qkv (no activation) and lin1 (GELU)
-            if (act == ACT_GELU) epilogue(std::integral_constant<int, ACT_GELU>{}, std::true_type{});
-            else epilogue(std::integral_constant<int, ACT_NONE>{}, std::true_type{});
-        } else if (act == ACT_GELU) epilogue(std::integral_constant<int, ACT_GELU>{}, std::false_type{});
+        if (act == ACT_GELU) epilogue(std::integral_constant<int, ACT_GELU>{}, std::false_type{});
         else if (act == ACT_RELU) epilogue(std::integral_constant<int, ACT_RELU>{}, std::false_type{});
         else epilogue(std::integral_constant<int, ACT_NONE>{}, std::false_type{});
     }

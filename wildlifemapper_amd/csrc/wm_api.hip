@@ -576,6 +576,19 @@ int launch_gemm16v5_foldp_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     return 0;
 }
 
+template <class T16, int BN>
+int launch_gemm16v5_foldc_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
+    using G = G3<BN, 4>;
+    constexpr int LDS = 3 * G::STAGE + 32 * BN * 4;
+    WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, false, false, true>, LDS));
+    count_variant(BN == 320 ? WM_GEMM_V5_320 : WM_GEMM_V5_256);       // the 16-bit-output instance, with the folded LayerNorm's epilogue
+    const int grid = (a.M / 256) * (a.N / BN);
+    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + 2.0 * a.M * a.N);
+    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, false, false, true>), dim3(grid), dim3(512), LDS, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias,
                   const float* res, int res_mod, float* out32, void* out16, int M, int N, int K, int act,
                   const GemmExtra& x = GemmExtra{}) {
@@ -602,6 +615,8 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
             if (out32 || res || !out16 || !x.fold_c1 || !bias || (act != ACT_NONE && act != ACT_GELU) || K % bn || K / bn > 4)
                 return fail("gemm16: the folded-LayerNorm form is 16-bit-only output, act none | GELU, K a multiple of %d with at most 4 tiles", bn);
             a.fold_stats = x.fold_stats; a.fold_c1 = x.fold_c1; a.fold_ntile = K / bn; a.fold_bn = (float)bn; a.fold_eps = x.fold_eps;
+            if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_foldc_t<BF16, 320>(h, s, a)), (launch_gemm16v5_foldc_t<FP16, 320>(h, s, a)));
+            return WM_BY_PREC((launch_gemm16v5_foldc_t<BF16, 256>(h, s, a)), (launch_gemm16v5_foldc_t<FP16, 256>(h, s, a)));
         }
         if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320>(h, s, a)), (launch_gemm16v5_t<FP16, 320>(h, s, a)));
         return WM_BY_PREC((launch_gemm16v5_t<BF16, 256>(h, s, a)), (launch_gemm16v5_t<FP16, 256>(h, s, a)));
