@@ -16,6 +16,7 @@ ap.add_argument("--act", type=int, default=0)
 ap.add_argument("--f32out", action="store_true")
 ap.add_argument("--ln", action="store_true", help="fused residual GEMM + LayerNorm (wm_op_gemm16_ln)")
 ap.add_argument("--residual", action="store_true", help="fp32 residual added in the epilogue (implies --f32out)")
+ap.add_argument("--packed", action="store_true", help="A and W in LDS-image order (as the engine feeds the block GEMMs)")
 a = ap.parse_args()
 M = a.batch * 4096
 shapes = {"qkv": (M, 3840, 1280), "proj": (M, 1280, 1280), "lin1": (M, 5120, 1280), "lin2": (M, 1280, 5120),
@@ -34,6 +35,11 @@ for name in names:
     bias = torch.randn(n, device=dev)
     res = torch.randn(m, n, device=dev) if a.residual else None
     f32 = a.f32out or a.residual
+    layout = 0
+    if a.packed:
+        from wildlifemapper_amd import _native as Nn
+        A, W = G.pack16(A), G.pack16(W)
+        layout = Nn.GEMM_W_PACKED | Nn.GEMM_A_PACKED
     if a.ln:
         from wildlifemapper_amd import _native as Nn
         code, dt = G.PRECS[a.prec]
@@ -51,12 +57,12 @@ for name in names:
         print(f"{name:5s} M={m} N={n} K={k} fused LN: {us:8.1f} us (each call synchronises)", flush=True)
         continue
     for _ in range(3):
-        G.gemm16(A, W, bias, residual=res, act=a.act, prec=a.prec, want32=f32, want16=not f32)
+        G.gemm16(A, W, bias, residual=res, act=a.act, prec=a.prec, want32=f32, want16=not f32, layout=layout)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
-        G.gemm16(A, W, bias, residual=res, act=a.act, prec=a.prec, want32=f32, want16=not f32)
+        G.gemm16(A, W, bias, residual=res, act=a.act, prec=a.prec, want32=f32, want16=not f32, layout=layout)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.iters
