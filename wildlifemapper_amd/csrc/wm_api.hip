@@ -342,6 +342,9 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
     count_variant(BN == 320 ? (a_in.residual ? WM_GEMM_V5_320_RES : WM_GEMM_V5_320) : (a_in.residual ? WM_GEMM_V5_256_RES : WM_GEMM_V5_256));
     const int grid = (a_in.M / 256) * (a_in.N / BN);
     Gemm16Args a = a_in;
+#if WM_DEV_TIMELINE
+    if (const char* e = getenv("WM_GEMM_GROUP_M")) { if (atoi(e) > 0) a.group_m = atoi(e); }     // dev build only: tile-order A/B
+#endif
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
 #if WM_DEV_TIMELINE
