@@ -72,15 +72,14 @@ typedef struct wm_config {
 #define WM_FP8_MLP 4
 #define WM_FP8_ALL 7
 
-/* wm_config.flags.  WM_CFG_FUSE_LN: the two residual GEMMs of a transformer block also produce the LayerNorm that
- * follows them (see wm_op_gemm16_ln) where the batch allows; results are bit-identical either way.  Off by default:
- * measured +0.5 % tiles/s on ViT-H B=4 (the GEMMs are power-limited).  Also: env WM_LN_FUSE=1. */
+/* wm_config.flags.  Bit 0 (WM_CFG_FUSE_LN, rounds 1-2: LayerNorm fused into the residual GEMMs' epilogues with an in-kernel
+ * exchange of row statistics between workgroups) is accepted and ignored: the folded LayerNorm below replaced it. */
 #define WM_CFG_FUSE_LN 1
 /* WM_CFG_FOLD_LN (round 3): the blocks' two LayerNorms run inside the GEMMs around them -- the residual GEMM's epilogue also
  * produces each row's statistics and a 16-bit copy of the row, the following qkv / lin1 GEMM multiplies that copy with
  * gamma (.) W and applies rstd (acc - mean c1) + c2 in its epilogue (csrc/gemm16_v5.h "Folded LayerNorm") -- so the residual
  * stream is not re-read by a LayerNorm kernel.  Results differ from the unfolded path within the operand rounding (the
- * rounding points move), they do not depend on the batch size.  Takes precedence over WM_CFG_FUSE_LN.  The Python drop-in
+ * rounding points move), they do not depend on the batch size.  The Python drop-in
  * sets it by default (WM_LN_FOLD=0 turns it off): +2.6 % tiles/s (ViT-H, B = 16), logits 2.3e-4 against 2.4e-4 unfolded.
  * It covers the blocks whose operands are fp16.  bf16-operand blocks keep their LayerNorm kernel unless
  * WM_CFG_FOLD_LN_BF16 is set as well: the folded weight gamma (.) W is rounded a second time, and with bf16's 8-bit mantissa
@@ -231,8 +230,8 @@ int wm_profile_read(wm_handle* h, wm_kclass_stat* out /* [WM_KCLASS_COUNT] */);
 #define WM_GEMM_V5_320_RES 6    /* gemm16v5_kernel<320>, fp32 residual by LDS-DMA (proj / lin2 of ViT-H) */
 #define WM_GEMM_V5_256 7        /* gemm16v5_kernel<256>, no residual */
 #define WM_GEMM_V5_256_RES 8    /* gemm16v5_kernel<256>, fp32 residual */
-#define WM_GEMM_V5_320_LNF 9    /* gemm16v5_kernel<320> + fused LayerNorm */
-#define WM_GEMM_V5_256_LNF 10   /* gemm16v5_kernel<256> + fused LayerNorm */
+#define WM_GEMM_V5_320_LNF 9    /* (rounds 1-2: fused-LayerNorm instance, no longer built; id kept) */
+#define WM_GEMM_V5_256_LNF 10
 #define WM_GEMM_FP8_320 11      /* gemm8_kernel<320>: MX-fp8 block-scaled MFMA (WM_PREC_FP8) */
 #define WM_GEMM_FP8_256 12      /* gemm8_kernel<256> */
 #define WM_GEMM_V5_320_FOLDP 13 /* gemm16v5_kernel<320> fp32 + residual + row statistics + 16-bit copy (folded LayerNorm, producer) */
@@ -311,16 +310,6 @@ int wm_op_gemm8(const void* a_dev, const void* w_dev, const float* wscale_dev, c
                 int M, int N, int K, int act, int precision, void* stream);
 /* fp32 -> e4m3 bytes, unit scale, round to nearest even, saturating at +-448 (n % 4 == 0) */
 int wm_op_cvt_f32_to_fp8(const float* in_dev, void* out_dev, int64_t n, void* stream);
-
-/* The transformer block's two residual updates fused with the LayerNorm that follows them
- * (image_encoder.py:200-203: x = shortcut + attn(...), then norm2(x); x = x + mlp(...), then the next block's norm1):
- * out_f32 = residual + A W^T + bias (residual may alias out_f32) and out_16 = LayerNorm(out_f32 rows; gamma, beta, eps).
- * Fails if the shape cannot be fused (M % 256, N % 320 or 256, at most 4 column tiles, enough tiles to fill the chip,
- * every row block's workgroups co-resident); wm_encoder_forward then uses wm_op_gemm16 + wm_op_layernorm, whose
- * 16-bit-only form computes the statistics the same way, so the results are bit-identical.  Synchronises the stream. */
-int wm_op_gemm16_ln(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev,
-                    float* out_f32_dev, void* out_16_dev, const float* gamma_dev, const float* beta_dev, float eps,
-                    int M, int N, int K, int precision, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution without bias over a 64x64 token grid as an implicit GEMM (no im2col
  * buffer): the second neck conv, image_encoder.py:113-119.  a [B,64,64,c_in] NHWC 16-bit,

@@ -77,18 +77,6 @@ def unpack16_torch(p: torch.Tensor) -> torch.Tensor:
     return out.view(rows, K)
 
 
-def gemm16_ln(a16, w16, bias, residual, gamma, beta, eps, prec="bf16"):
-    """x = residual + a w^T + bias (in a copy of residual), LayerNorm(x) in 16 bits.  Returns (x32, ln16)."""
-    code, dt = PRECS[prec]
-    M, K = a16.shape
-    Nn = w16.shape[0]
-    x = residual.clone()
-    o16 = torch.empty((M, Nn), device=a16.device, dtype=dt)
-    N.check(N.lib().wm_op_gemm16_ln(N.ptr(a16), N.ptr(w16), N.ptr(bias), N.ptr(x), N.ptr(x), N.ptr(o16), N.ptr(gamma), N.ptr(beta),
-                                    eps, M, Nn, K, code, sp()))
-    return x, o16
-
-
 def fold_bn(C):
     return 320 if C % 320 == 0 else 256
 

@@ -382,40 +382,6 @@ def test_gemm16_kernels_agree_bitwise():
     assert torch.equal(big16[:256], sm16)
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16"])
-@pytest.mark.parametrize("M,N,K", [(16384, 1280, 256), (12288, 768, 512), (16384, 1024, 64), (49152, 1280, 64)])   # 256 / 144 / 256 workgroups, 3 rounds
-def test_gemm16_ln_fused(prec, M, N, K):
-    """Residual GEMM + LayerNorm in one launch (row statistics exchanged between the column-tile workgroups) against
-    the two separate ops.  Rows get distinct means / scales so a mixed-up row or partial would show."""
-    dev = G.dev()
-    a = G.to16(torch.randn(M, K, device=dev), prec)
-    w = G.to16(torch.randn(N, K, device=dev) / math.sqrt(K), prec)
-    bias = torch.randn(N, device=dev)
-    res = torch.randn(M, N, device=dev) * (0.5 + torch.rand(M, 1, device=dev) * 4) + torch.randn(M, 1, device=dev) * 3
-    gamma = 1 + 0.2 * torch.randn(N, device=dev)
-    beta = 0.3 * torch.randn(N, device=dev)
-    for _ in range(3):                                   # consecutive launches reuse the arrival counters (epochs)
-        x, ln16 = G.gemm16_ln(a, w, bias, res, gamma, beta, 1e-6, prec)
-    want_x = res + a.float() @ w.float().t() + bias
-    assert G.rel_l2(x, want_x) < 1e-5
-    want_ln = torch.nn.functional.layer_norm(want_x, (N,), gamma, beta, 1e-6)
-    assert G.rel_l2(ln16.float(), want_ln) < OUT16_TOL[prec]
-    # bit-identical to the unfused twin (layernorm_tiled_kernel shares the statistics' arithmetic): which of the two runs
-    # depends on the batch size, and a tile's result must not
-    if N > 1280:
-        return                                           # the separate kernels stop at 1280 channels
-    _, ln_sep = G.layernorm(x, gamma, beta, 1e-6, prec, want32=False, want16=True)
-    assert torch.equal(ln16, ln_sep)
-
-
-def test_gemm16_ln_rejects_unfusable():
-    a = G.to16(torch.randn(256, 64, device=G.dev()), "bf16")
-    w = G.to16(torch.randn(384, 64, device=G.dev()), "bf16")
-    z = torch.zeros(256, 384, device=G.dev())
-    with pytest.raises(RuntimeError, match="cannot be fused"):
-        G.gemm16_ln(a, w, torch.zeros(384, device=G.dev()), z, torch.ones(384, device=G.dev()), torch.zeros(384, device=G.dev()), 1e-6)
-
-
 def test_gelu_fast_accuracy():
     """The 16-bit GEMM epilogue's GELU (degree-3/3 rational erf, wm_common.h) against the exact-erf form, fp32 output:
     C[m][n] = a[m][0] * w[n][0] with power-of-two row scales sweeps x over [-9, 9] exactly."""

@@ -33,8 +33,7 @@ namespace wm {
 // DBG (dev only, WM_GEMM_DBG=1, see launch_gemm16v5_t): waves 0 and 4 of workgroup 0 record s_memtime at six marks of
 // K-steps 8..17, every workgroup its wall-clock entry / first barrier / loop end / stores-acknowledged stamps, into
 // p.zero_page.  The instrumented instance is a separate kernel; the product instance carries none of it.
-// (LNF, rounds 1-2: the fp32-residual epilogue also LayerNormed the finished rows, the row block's workgroups exchanging their
-// statistics in-kernel: zero net gain, superseded by the folded LayerNorm below; tools/experiments/gemm16_v5_lnf_fused_layernorm.h.)
+// LNF: the fp32-residual epilogue also LayerNorms the finished rows (see its code and Gemm16Args::ln_*).
 // (A persistent instance -- one workgroup per CU walking its tiles and prefetching the next tile's first K-steps during the
 // epilogue -- was built in round 2, bit-identical and 7-15 % slower: tools/experiments/gemm16_v5_persist.h)
 // Operand layout (round 3).  A DMA piece is 1 KiB of LDS: 16 rows x 64 B of one K-step.  Read from a row-major operand
@@ -63,9 +62,9 @@ namespace wm {
 // included); fp16's range holds for |x| < 65504 (the saturation census watches this buffer).
 // (FOLDC, the consumer, is an instance of its own: compiled into the plain instance its extra epilogue state cost that kernel
 // 114 spilled registers.)
-template <class T, int BN, int NSLOT = 3, bool DBG = false, bool FOLDP = false, bool FOLDC = false>
+template <class T, int BN, int NSLOT = 3, bool DBG = false, bool LNF = false, bool FOLDP = false, bool FOLDC = false>
 __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
-    static_assert(!(FOLDC && (FOLDP || DBG)), "the folded-LayerNorm consumer is the plain 16-bit-output kernel");
+    static_assert(!(FOLDC && (LNF || FOLDP || DBG)), "the folded-LayerNorm consumer is the plain 16-bit-output kernel");
     using C = G3<BN, 4>;
     constexpr int AHEAD = NSLOT - 1;                       // K-steps of DMA in flight
     // timing experiments of tools/gemm_bench.py (--act 256 / 512 / 1024): compiled in only with -DWM_GEMM_TIMING_BITS=1
@@ -367,7 +366,116 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
                 barrier();
             }
         }
-    } else if (p.out32 == nullptr && p.residual == nullptr) {
+    } else
+    if constexpr (LNF) {
+        // ---- residual + LayerNorm (proj -> norm2, lin2 -> the next block's norm1; image_encoder.py:200-203) ----
+        // The separate LayerNorm kernel re-read the 84 MB fp32 residual stream this epilogue has just produced.  Here a
+        // thread keeps its share of the finished tile in the registers the accumulators free up (a 16-lane group owns
+        // a row of the pass: 80 chunks = 5 per lane), the workgroup computes each row's (mean, M2) over its BN columns
+        // two-pass, publishes them with sc1 stores, adds to the row block's arrival counter, waits for its N / BN - 1
+        // partners (co-resident: launch_gemm16 fuses only when the grid fits the chip or row blocks never straddle a
+        // round), combines the partials (Chan) and normalises from registers.  Hand-off per MI355X_MICROARCH.md
+        // "inter-workgroup visibility": sc1 payload stores, every wave's vmcnt(0), barrier, one agent-scope atomic add;
+        // consumer: sc1 poll by one lane, barrier, sc1 loads.  The poll is bounded: a lost partner costs wrong
+        // numbers in this row block (and sets ln_counter[-1]), never a hang.
+        constexpr int ROWB = BN * 4 + 16, CPT = RP_CPR / 16;
+        constexpr int STAT_OFF = 90112;                      // [256][2] fp32 behind the second landing buffer
+        static_assert(RES_L1 + RES_BYTES <= STAT_OFF && STAT_OFF + 2048 <= NSLOT * C::STAGE, "epilogue LDS map");
+        float* rowstat = (float*)(smem + STAT_OFF);
+        const int r = tid >> 4, l16 = tid & 15;              // row of the pass, position in the row's 16-lane group
+        f32x4 vk[C::MT][CPT];
+#pragma unroll
+        for (int q = 0; q < C::MT; ++q) {
+            if (q + 1 < C::MT) res_dma(q + 1);
+#pragma unroll
+            for (int ni = 0; ni < C::NT; ++ni)
+                *(f32x4*)(smem + (wr * 16 + fr) * ROWB + (wc * C::WCOLS + ni * 16 + fq * 4) * 4) = finish(acc[q][ni], ni);
+            if (q + 1 < C::MT) wait_vmcnt<RP_PW>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            barrier();
+            const char* land = smem + ((q & 1) ? RES_L1 : RES_L0);
+            const int tl = (r >> 4) * 128 + q * 16 + (r & 15);          // row in the tile
+#pragma unroll
+            for (int kk = 0; kk < CPT; ++kk) {
+                const int ch = l16 + 16 * kk;
+                const f32x4 v = *(const f32x4*)(smem + r * ROWB + ch * 16) + *(const f32x4*)(land + (r * RP_CPR + ch) * 16);
+                *(f32x4*)(p.out32 + (size_t)(m0 + tl) * p.N + n0 + ch * 4) = v;
+                vk[q][kk] = v;
+            }
+            float mean, m2;
+            ln_partial16<CPT>(vk[q], 1.0f / BN, mean, m2);
+            if (l16 == 0) { rowstat[tl * 2] = mean; rowstat[tl * 2 + 1] = m2; }
+            if (q + 1 < C::MT) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                barrier();
+            }
+        }
+        const int ntile = p.N / BN, nt = n0 / BN, mt = m0 / C::BM;
+        unsigned long long lt1 = 0, lt2 = 0, lt3 = 0;
+        if (p.zero_page) lt1 = wall_clock64();
+        __syncthreads();
+        if (tid < C::BM) {
+            const unsigned long long pay = ((unsigned long long)__float_as_uint(rowstat[tid * 2 + 1]) << 32) | __float_as_uint(rowstat[tid * 2]);
+            __hip_atomic_store((unsigned long long*)p.ln_stats + ((size_t)(m0 + tid) * ntile + nt), pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (p.zero_page) lt2 = wall_clock64();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(p.ln_counter + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int target = ntile * p.ln_epoch;
+            int budget = 200000;
+            if (dbg_noissue) budget = 1;                  // timing experiment: do not wait for the partners
+            while (__hip_atomic_load(p.ln_counter + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && --budget > 0)
+                __builtin_amdgcn_s_sleep(24);             // ~0.8 us between polls: a fast poll loop of 190 lanes slows the partners down
+            if (budget <= 0 && !dbg_noissue) __hip_atomic_store(p.ln_counter - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid < C::BM) {
+            float mk[8], qk2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                mk[i] = qk2[i] = 0.f;
+                if (i < ntile) {
+                    const unsigned long long pay = __hip_atomic_load((unsigned long long*)p.ln_stats + ((size_t)(m0 + tid) * ntile + i),
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mk[i] = __uint_as_float((unsigned)pay);
+                    qk2[i] = __uint_as_float((unsigned)(pay >> 32));
+                }
+            }
+            float rstd;
+            const float mean = ln_combine(mk, qk2, ntile, (float)BN, (float)p.N, p.ln_eps, rstd);
+            rowstat[tid * 2] = mean;
+            rowstat[tid * 2 + 1] = rstd;
+        }
+        __syncthreads();
+        if (p.zero_page) lt3 = wall_clock64();
+        f32x4 gv[CPT], bv[CPT];
+#pragma unroll
+        for (int kk = 0; kk < CPT; ++kk) {
+            gv[kk] = *(const f32x4*)(p.ln_gamma + n0 + (l16 + 16 * kk) * 4);
+            bv[kk] = *(const f32x4*)(p.ln_beta + n0 + (l16 + 16 * kk) * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < C::MT; ++q) {
+            const int tl = (r >> 4) * 128 + q * 16 + (r & 15);
+            const float mean = rowstat[tl * 2], rstd = rowstat[tl * 2 + 1];
+#pragma unroll
+            for (int kk = 0; kk < CPT; ++kk) {
+                typename T::vec4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = T::from_f32(ln_apply(vk[q][kk][j], mean, rstd, gv[kk][j], bv[kk][j]));
+                if (dbg_nostore) { if (o[0] == (typename T::elem)12345.0f) p.out16[0] = 1; continue; }
+                *(typename T::vec4*)(p.out16 + (size_t)(m0 + tl) * p.N + n0 + (l16 + 16 * kk) * 4) = o;
+            }
+        }
+        if (p.zero_page && tid == 0) {                       // dev timeline (WM_LNF_TIMELINE): 10 ns wall-clock stamps per workgroup
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long* rec = (unsigned long long*)p.zero_page + (size_t)blockIdx.x * 4;
+            rec[0] = lt1; rec[1] = lt2; rec[2] = lt3; rec[3] = wall_clock64();
+        }
+    } else
+    if (p.out32 == nullptr && p.residual == nullptr) {
         // 16-bit staging: 2 passes of 4 row-fragments; LDS row = BN * 2 + 16 bytes
         constexpr int ROWB = BN * 2 + 16, CPR = BN * 2 / 16, MTP = 4, ROWS = 2 * MTP * 16;
         static_assert(EPI_BASE + ROWS * ROWB <= LDS_TOTAL && (ROWS * CPR) % 512 == 0, "epilogue staging");
@@ -503,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         }
     }
     };
-    if constexpr (FOLDP) {
+    if constexpr (LNF || FOLDP) {
         epilogue(std::integral_constant<int, ACT_NONE>{}, std::false_type{});
     } else if constexpr (FOLDC) {                            // folded LayerNorm: the 16-bit-output GEMMs qkv (no activation) and lin1 (GELU)
         if (act == ACT_GELU) epilogue(std::integral_constant<int, ACT_GELU>{}, std::true_type{});

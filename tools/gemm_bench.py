@@ -14,7 +14,6 @@ ap.add_argument("--prec", default="bf16")
 ap.add_argument("--custom", default="", help="semicolon-separated M,N,K triples")
 ap.add_argument("--act", type=int, default=0)
 ap.add_argument("--f32out", action="store_true")
-ap.add_argument("--ln", action="store_true", help="fused residual GEMM + LayerNorm (wm_op_gemm16_ln)")
 ap.add_argument("--residual", action="store_true", help="fp32 residual added in the epilogue (implies --f32out)")
 ap.add_argument("--packed", action="store_true", help="A and W in LDS-image order (as the engine feeds the block GEMMs)")
 a = ap.parse_args()
@@ -40,22 +39,6 @@ for name in names:
         from wildlifemapper_amd import _native as Nn
         A, W = G.pack16(A), G.pack16(W)
         layout = Nn.GEMM_W_PACKED | Nn.GEMM_A_PACKED
-    if a.ln:
-        from wildlifemapper_amd import _native as Nn
-        code, dt = G.PRECS[a.prec]
-        x = torch.randn(m, n, device=dev); o16 = torch.empty(m, n, device=dev, dtype=dt)
-        gam = torch.ones(n, device=dev); bet = torch.zeros(n, device=dev)
-        def run():
-            Nn.check(Nn.lib().wm_op_gemm16_ln(Nn.ptr(A), Nn.ptr(W), Nn.ptr(bias), Nn.ptr(x), Nn.ptr(x), Nn.ptr(o16), Nn.ptr(gam), Nn.ptr(bet), 1e-6, m, n, k, code, G.sp()))
-        for _ in range(3): run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters): run()
-        e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / a.iters
-        print(f"{name:5s} M={m} N={n} K={k} fused LN: {us:8.1f} us (each call synchronises)", flush=True)
-        continue
     for _ in range(3):
         G.gemm16(A, W, bias, residual=res, act=a.act, prec=a.prec, want32=f32, want16=not f32, layout=layout)
     torch.cuda.synchronize()

@@ -81,7 +81,6 @@ SYMBOLS = {
     "wm_op_fold_weight16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "wm_op_gemm16_folded": (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P]),
     "wm_op_gemm16_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "wm_op_gemm16_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
     "wm_op_gemm8": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm_op_cvt_f32_to_fp8": (_I, [_P, _P, _L, _P]),
     "wm_op_conv3x3_16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

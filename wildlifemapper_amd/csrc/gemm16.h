@@ -44,16 +44,6 @@ struct Gemm16Args {
     // `zero_page` (>= 64 B of zeros).  Unused (0 / null) for a plain A matrix.
     int conv_c;
     const u16* zero_page;
-    // Fused LayerNorm of the output rows (gemm16_v5.h, LNF instance): out16 = LN(out32 row; ln_gamma, ln_beta, ln_eps)
-    // over all N columns.  The N / BN workgroups of a row block exchange per-row (mean, M2) through ln_stats
-    // ([M][N / BN][2] fp32) and the per-row-block arrival counter ln_counter[M / 256], which reaches
-    // (N / BN) * ln_epoch when every partner of THIS launch has published.  Null / 0 otherwise.
-    const float* ln_gamma;
-    const float* ln_beta;
-    float ln_eps;
-    float* ln_stats;
-    int* ln_counter;
-    int ln_epoch;
     // row tiles per group of the grouped tile order (gemm16_v5.h; 0 = G16_GROUP_M): a group's row tiles x all column tiles
     // are consecutive tile ids, so group_m * tilesN ~ the 32 workgroups co-resident on an XCD keeps each A panel to one XCD
     int group_m;

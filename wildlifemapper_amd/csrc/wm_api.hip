@@ -30,7 +30,7 @@
 #include "wm_common.h"
 
 // Dev instrumentation (in-kernel timelines of the GEMMs: tools/gemm_bench.py with WM_GEMM_DBG / WM_GEMM8_DBG /
-// WM_LNF_TIMELINE) is compiled only with -DWM_DEV_TIMELINE=1 (tools/build_dev.sh); the product library carries neither
+// WM_GEMM8_DBG) is compiled only with -DWM_DEV_TIMELINE=1 (tools/build_dev.sh); the product library carries neither
 // the instrumented kernel instances nor their environment switches.
 #ifndef WM_DEV_TIMELINE
 #define WM_DEV_TIMELINE 0
@@ -202,19 +202,8 @@ struct Profiler {
 
 }  // namespace
 
-// Workspace of the fused residual GEMM + LayerNorm (gemm16_v5.h, LNF instance): per-row partial statistics and the row
-// blocks' arrival counters; counter_base[0] is the "a partner never arrived" flag.  The counters only ever grow: a
-// launch's target is tiles_N * epoch, so the epoch restarts (with a memset) whenever the geometry changes.  One per
-// handle (launches of one handle are stream-ordered), plus one for the handle-less single-op entry.
-struct LnFuseState {
-    float* stats = nullptr;       // [M][ntile][2]
-    int* counter_base = nullptr;  // [1 + mtiles]
-    size_t stats_floats = 0;
-    int counters = 0, epoch = 0, geom = -1;
-};
 struct wm_handle {
     wm_config cfg{};
-    LnFuseState lnf;
     int fp8_gemms = WM_FP8_ALL;             // fp8 mode: which of a block's GEMMs run e4m3 (wm_config.fp8_gemms, 0 = all)
     int fp8_bf16_tail = 0, fp8_bf16_head = 0;  // fp8 mode: the first / last blocks that stay bf16 (env WM_FP8_BF16_HEAD / _TAIL, default 0)
     int fp16_tail = 0;      // bf16 mode: the last fp16_tail transformer blocks use fp16 operands (parity margin dial; default 0)
@@ -412,119 +401,6 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
     return 0;
 }
 
-// ---- fused residual GEMM + LayerNorm (gemm16_v5.h, LNF instance) ----
-static LnFuseState g_lnf;
-
-// Which column tile the fused kernel would use, or 0 if this shape must keep the separate LayerNorm kernel: every
-// workgroup of a row block has to be resident together, i.e. the grid fits the chip, or the XCD remap hands each XCD
-// whole groups of 8 row blocks (then a round never splits a row block).
-static int ln_fuse_bn(int M, int N, int K) {
-    if (M % 256 || K % 32 || K / 32 < 2) return 0;
-    const int bn = N % 320 == 0 ? 320 : (N % 256 == 0 ? 256 : 0);
-    if (!bn) return 0;
-    const int tn = N / bn, nwg = (M / 256) * tn;
-    if (tn > 4) return 0;                                  // layernorm_tiled_kernel (the unfused twin) holds 4 column tiles
-    if ((double)((2L * nwg + 255) / 256) * 0.6 < (double)((nwg + 255) / 256)) return 0;   // too few tiles: launch_gemm16 prefers the half-width kernel
-    if (nwg <= num_cus()) return bn;
-    if (nwg % 8 == 0 && (nwg / 8) % (G16_GROUP_M * tn) == 0 && (M / 256) % G16_GROUP_M == 0) return bn;
-    return 0;
-}
-
-template <class T16, int BN>
-int launch_gemm16v5_ln_t(wm_handle* h, hipStream_t s, Gemm16Args a) {
-    using G = G3<BN, 4>;
-    constexpr int LDS = 3 * G::STAGE + 32 * BN * 4;
-    WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, true>, LDS));
-    count_variant(BN == 320 ? WM_GEMM_V5_320_LNF : WM_GEMM_V5_256_LNF);
-    LnFuseState& g_lnf = h ? h->lnf : ::g_lnf;
-    const int mtiles = a.M / 256, tn = a.N / BN;
-    const size_t need = (size_t)a.M * tn * 2;
-    if (need > g_lnf.stats_floats) {
-        if (g_lnf.stats) HIP_TRY(hipFree(g_lnf.stats));
-        g_lnf.stats = nullptr; g_lnf.stats_floats = 0;
-        HIP_TRY(hipMalloc((void**)&g_lnf.stats, need * 4));
-        g_lnf.stats_floats = need;
-    }
-    if (mtiles + 1 > g_lnf.counters) {
-        if (g_lnf.counter_base) HIP_TRY(hipFree(g_lnf.counter_base));
-        g_lnf.counter_base = nullptr; g_lnf.counters = 0;
-        HIP_TRY(hipMalloc((void**)&g_lnf.counter_base, (size_t)(mtiles + 1) * 4));
-        g_lnf.counters = mtiles + 1;
-        g_lnf.geom = -1;
-    }
-    const int geom = mtiles * 16 + tn;
-    if (geom != g_lnf.geom || g_lnf.epoch > (1 << 26)) {
-        HIP_TRY(hipMemsetAsync(g_lnf.counter_base, 0, (size_t)g_lnf.counters * 4, s));
-        g_lnf.geom = geom;
-        g_lnf.epoch = 0;
-    }
-    a.ln_stats = g_lnf.stats;
-    a.ln_counter = g_lnf.counter_base + 1;
-    a.ln_epoch = ++g_lnf.epoch;
-    const int grid = mtiles * tn;
-    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
-               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + 10.0 * a.M * a.N);
-#if WM_DEV_TIMELINE
-    static const bool timeline = getenv("WM_LNF_TIMELINE") != nullptr;       // dev: per-workgroup stamps of the fused epilogue
-    static int tl_count = 0;
-    if (timeline && ++tl_count == 12) {
-        static unsigned long long* buf = nullptr;
-        if (!buf) HIP_TRY(hipMalloc((void**)&buf, 8192 * 32));
-        if (grid > 8192) return fail("timeline grid");
-        a.zero_page = (const u16*)buf;
-        hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, true>), dim3(grid), dim3(512), LDS, s, a);
-        HIP_TRY(hipStreamSynchronize(s));
-        std::vector<unsigned long long> hb((size_t)grid * 4);
-        HIP_TRY(hipMemcpy(hb.data(), buf, hb.size() * 8, hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull;
-        for (int i = 0; i < grid; ++i) t0 = std::min(t0, hb[i * 4]);
-        double a1 = 0, a2 = 0, a3 = 0, m1 = 0, m3 = 0, mx_end = 0, mn1 = 1e30;
-        for (int i = 0; i < grid; ++i) {
-            const double passA = (hb[i * 4] - t0) * 0.01, pub = (hb[i * 4 + 1] - hb[i * 4]) * 0.01, wait = (hb[i * 4 + 2] - hb[i * 4 + 1]) * 0.01,
-                         passB = (hb[i * 4 + 3] - hb[i * 4 + 2]) * 0.01;
-            a1 += pub; a2 += wait; a3 += passB; m1 = std::max(m1, passA); mn1 = std::min(mn1, passA); m3 = std::max(m3, wait);
-            mx_end = std::max(mx_end, (hb[i * 4 + 3] - t0) * 0.01);
-        }
-        fprintf(stderr, "[gemm16v5 LNF timeline] M=%d N=%d K=%d: pass A ends spread over %.2f us; publish avg %.2f us; wait avg %.2f max %.2f us; "
-                "pass B avg %.2f us; last workgroup done %.2f us after the first pass-A end\n", a.M, a.N, a.K, m1 - mn1, a1 / grid, a2 / grid, m3, a3 / grid, mx_end);
-        return 0;
-    }
-#endif
-    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, true>), dim3(grid), dim3(512), LDS, s, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// out32 = residual + A W^T + bias (residual may alias out32), out16 = LayerNorm(out32 rows).  Returns 1 (and launches
-// nothing) when the shape cannot be fused; the caller then runs the GEMM and the LayerNorm kernel separately.
-int launch_gemm16_ln(wm_handle* h, hipStream_t s, int prec, const void* A, const void* W, const float* bias, const float* res,
-                     float* out32, void* out16, const float* gamma, const float* beta, float eps, int M, int N, int K,
-                     const void* Wp = nullptr, int a_packed = 0) {
-    const bool off = h && !(h->cfg.flags & WM_CFG_FUSE_LN);          // engine: opt-in; the single-op entry always fuses
-    const int bn = ln_fuse_bn(M, N, K);
-    if (off || !bn || !res || !out32 || !out16 || !gamma || !beta) return 1;
-    constexpr int dbg_bits = 0;
-    Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, 0, ACT_NONE | dbg_bits, 0, nullptr, gamma, beta, eps, nullptr, nullptr, 0};
-    if (Wp) { a.W = (const u16*)Wp; a.w_packed = 1; }
-    a.a_packed = a_packed;
-    if (bn == 320) return prec == WM_PREC_FP16 ? launch_gemm16v5_ln_t<FP16, 320>(h, s, a) : launch_gemm16v5_ln_t<BF16, 320>(h, s, a);
-    return prec == WM_PREC_FP16 ? launch_gemm16v5_ln_t<FP16, 256>(h, s, a) : launch_gemm16v5_ln_t<BF16, 256>(h, s, a);
-}
-
-// 1 if some fused launch gave up waiting for a partner workgroup (results of that launch are wrong); clears the flag
-int ln_fuse_check(wm_handle* h, hipStream_t s) {
-    LnFuseState& g_lnf = h ? h->lnf : ::g_lnf;
-    if (!g_lnf.counter_base) return 0;
-    int flag = 0;
-    HIP_TRY(hipMemcpyAsync(&flag, g_lnf.counter_base, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (flag) {
-        HIP_TRY(hipMemsetAsync(g_lnf.counter_base, 0, 4, s));
-        return fail("fused GEMM + LayerNorm: a workgroup timed out waiting for its row-block partners");
-    }
-    return 0;
-}
-
 // fraction of the last round of workgroup slots that is filled
 static double round_eff(long tiles, long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); }
 
@@ -569,12 +445,12 @@ template <class T16, int BN>
 int launch_gemm16v5_foldp_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     using G = G3<BN, 4>;
     constexpr int LDS = 3 * G::STAGE + 32 * BN * 4;
-    WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, false, true>, LDS));
+    WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, true>, LDS));
     count_variant(BN == 320 ? WM_GEMM_V5_320_FOLDP : WM_GEMM_V5_256_FOLDP);
     const int grid = (a.M / 256) * (a.N / BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + 10.0 * a.M * a.N);
-    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, false, true>), dim3(grid), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, true>), dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -583,11 +459,11 @@ template <class T16, int BN>
 int launch_gemm16v5_foldc_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     using G = G3<BN, 4>;
     constexpr int LDS = 3 * G::STAGE + 32 * BN * 4;
-    WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, false, false, true>, LDS));
+    WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, false, true>, LDS));
     count_variant(BN == 320 ? WM_GEMM_V5_320 : WM_GEMM_V5_256);       // the 16-bit-output instance, with the folded LayerNorm's epilogue
     const int grid = (a.M / 256) * (a.N / BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K) + 2.0 * a.M * a.N);
-    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, false, false, true>), dim3(grid), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, false, true>), dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -753,7 +629,7 @@ int launch_layernorm(wm_handle* h, hipStream_t s, int prec, const float* x, cons
 }
 
 // LayerNorm of the transformer blocks (norm1 / norm2, 16-bit output): column-tiled statistics, bit-identical to the
-// LayerNorm fused into the residual GEMMs (launch_gemm16_ln), so results do not depend on which of the two ran.
+// (the same statistics arithmetic as the folded LayerNorm's producers: ln_partial16 / ln_combine).
 int launch_layernorm_block(wm_handle* h, hipStream_t s, int prec, const float* x, const float* g, const float* b, float eps,
                            void* out16, int64_t rows, int C, int packed = 0) {
     const int bn = C % 320 == 0 ? 320 : (C % 256 == 0 ? 256 : 0);
@@ -1130,8 +1006,6 @@ extern "C" int wm_destroy(wm_handle* h) {
     hipDeviceSynchronize();
     for (void* p : h->allocs) if (p) hipFree(p);
     if (h->tap_buf) hipFree(h->tap_buf);
-    if (h->lnf.stats) hipFree(h->lnf.stats);
-    if (h->lnf.counter_base) hipFree(h->lnf.counter_base);
     for (auto& e : h->prof.used) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : h->prof.pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete h;
@@ -1412,14 +1286,12 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     WM_TRY(do_tap(h, s, -1, B));
 
     // ---- transformer blocks (image_encoder.py:188-204) ----
-    // x = x + proj(attn(norm1 x)); x = x + lin2(gelu(lin1(norm2 x))).  The two residual GEMMs also produce the following
-    // LayerNorm's output where the shape allows (launch_gemm16_ln returns 1 otherwise and the separate kernels run).
+    // x = x + proj(attn(norm1 x)); x = x + lin2(gelu(lin1(norm2 x))).
     // Per GEMM the operand type is the block's (block_prec) or, in fp8 mode, e4m3 for the GEMMs the handle's fp8 mask names
     // (WM_FP8_QKV | WM_FP8_PROJ | WM_FP8_MLP; lin1 and lin2 go together because lin1's epilogue writes lin2's operand) and
     // bf16 for the rest and for attention.  Each producer writes its consumer's operand type directly (LayerNorm / attention /
     // GELU epilogue -> e4m3 bytes or 16-bit), so no conversion pass exists in any mix.
-    bool xn_ready = false;                                  // xn16 already holds norm1 of the current residual stream
-    bool xn_packed = false;                                 // ... in LDS-image order
+    bool xn_packed = false;                                 // xn16 (a LayerNorm's output) is in LDS-image order
     for (int i = 0; i < h->depth; ++i) {
         const std::string b = e + "blocks." + std::to_string(i) + ".";
         const int PB = block_prec(h, i);
@@ -1467,15 +1339,12 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
                                      h->resid, produce ? h->xn16 : nullptr, M, D, 4 * D, ACT_NONE, x));
                 raw_prec = produce ? P : -1;
             }
-            xn_ready = false;
             WM_TRY(do_tap(h, s, i, B));
             continue;
         }
         raw_prec = -1;
-        if (!xn_ready) {
-            WM_TRY(launch_layernorm_block(h, s, q8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D, pk_qkv));
-            xn_packed = pk_qkv;
-        }
+        WM_TRY(launch_layernorm_block(h, s, q8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D, pk_qkv));
+        xn_packed = pk_qkv;
         WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, q8 ? WM_PREC_FP8 : P));
         if (q8)
             WM_TRY(launch_gemm8(h, s, P, h->xn16, W8(b + "attn.qkv.weight"), W32(h, b + "attn.qkv.weight.wscale"), W32(h, b + "attn.qkv.bias"),
@@ -1489,26 +1358,16 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
                                         W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14, p8 ? h->ao8 : nullptr));
         if (p8) WM_TRY(sat_check(h, s, WM_SAT_ATTN, h->ao8, (int64_t)M * D, WM_PREC_FP8));
         else WM_TRY(sat_check(h, s, WM_SAT_ATTN, h->ao16, (int64_t)M * D, P));
-        bool n2_ready = false;                              // xn16 holds norm2 of the updated residual stream
         if (p8) {
             WM_TRY(launch_gemm8(h, s, P, h->ao8, W8(b + "attn.proj.weight"), W32(h, b + "attn.proj.weight.wscale"), W32(h, b + "attn.proj.bias"),
                                 h->resid, h->resid, nullptr, nullptr, M, D, D, ACT_NONE));
         } else {
-            int r = m8 ? 1 : launch_gemm16_ln(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, h->resid,
-                                              h->xn16, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, M, D, D, W16P(h, b + "attn.proj.weight"));
-            if (r < 0) return r;
-            n2_ready = r == 0;
-            if (n2_ready) xn_packed = false;                 // the fused epilogue writes its LayerNorm output row-major
-            if (r == 1)
-                WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
-                                     h->resid, nullptr, M, D, D, ACT_NONE, GX(W16P(h, b + "attn.proj.weight"))));
+            WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
+                                 h->resid, nullptr, M, D, D, ACT_NONE, GX(W16P(h, b + "attn.proj.weight"))));
         }
-        if (!n2_ready) {
-            WM_TRY(launch_layernorm_block(h, s, m8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D, pk_lin1));
-            xn_packed = pk_lin1;
-        }
+        WM_TRY(launch_layernorm_block(h, s, m8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D, pk_lin1));
+        xn_packed = pk_lin1;
         WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, m8 ? WM_PREC_FP8 : P));
-        xn_ready = false;
         if (m8) {
             WM_TRY(launch_gemm8(h, s, P, h->xn16, W8(b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.weight.wscale"), W32(h, b + "mlp.lin1.bias"),
                                 nullptr, nullptr, nullptr, h->hid16, M, 4 * D, D, ACT_GELU));
@@ -1519,19 +1378,8 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
             WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.bias"), nullptr, 0, nullptr,
                                  h->hid16, M, 4 * D, D, ACT_GELU, GX(W16P(h, b + "mlp.lin1.weight"), xn_packed, pk_lin2)));
             WM_TRY(sat_check(h, s, WM_SAT_HID, h->hid16, (int64_t)M * 4 * D, P));
-            // the fused kernel's operand type is also its LayerNorm output type: the next block's norm1 must want the same
-            if (i + 1 < h->depth && block_prec(h, i + 1) == PB && !f8) {
-                const std::string nb = e + "blocks." + std::to_string(i + 1) + ".";
-                int r = launch_gemm16_ln(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, h->resid,
-                                         h->xn16, W32(h, nb + "norm1.weight"), W32(h, nb + "norm1.bias"), 1e-6f, M, D, 4 * D,
-                                         W16P(h, b + "mlp.lin2.weight"), pk_lin2);
-                if (r < 0) return r;
-                xn_ready = r == 0;
-                if (xn_ready) xn_packed = false;
-            }
-            if (!xn_ready)
-                WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
-                                     h->resid, nullptr, M, D, 4 * D, ACT_NONE, GX(W16P(h, b + "mlp.lin2.weight"), pk_lin2)));
+            WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
+                                 h->resid, nullptr, M, D, 4 * D, ACT_NONE, GX(W16P(h, b + "mlp.lin2.weight"), pk_lin2)));
         }
         WM_TRY(do_tap(h, s, i, B));
     }
@@ -1672,7 +1520,6 @@ extern "C" int wm_encoder_forward(wm_handle* h, const float* x_dev, const float*
     WM_TRY(encoder_impl(h, x_dev, hfc_dev, out_dev, batch, (hipStream_t)stream));
     // opt-in fused GEMM + LayerNorm: a partner time-out means wrong numbers, so it must never pass silently; the check
     // reads the flag on the launch stream (one stream synchronisation per call, paid only with the option on)
-    if (h->cfg.flags & WM_CFG_FUSE_LN) WM_TRY(ln_fuse_check(h, (hipStream_t)stream));
     return 0;
 }
 
@@ -1708,7 +1555,6 @@ extern "C" int wm_forward(wm_handle* h, const float* x_dev, const float* target_
     if (logits_dev) HIP_TRY(hipMemcpyAsync(logits_dev, h->logits, (size_t)batch * NQ * WM_NUM_LOGITS * 4, hipMemcpyDeviceToDevice, s));
     if (boxes_dev) HIP_TRY(hipMemcpyAsync(boxes_dev, h->boxes, (size_t)batch * NQ * 16, hipMemcpyDeviceToDevice, s));
     if (records_dev) HIP_TRY(hipMemcpyAsync(records_dev, h->records, (size_t)batch * NQ * sizeof(wm_box_record), hipMemcpyDeviceToDevice, s));
-    if (h->cfg.flags & WM_CFG_FUSE_LN) WM_TRY(ln_fuse_check(h, s));     // see wm_encoder_forward
     return 0;
 }
 
@@ -2009,18 +1855,6 @@ extern "C" int wm_op_pack16(const void* in_dev, void* out_dev, int64_t rows, int
     return 0;
 }
 
-extern "C" int wm_op_gemm16_ln(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev,
-                               float* out_f32_dev, void* out_16_dev, const float* gamma_dev, const float* beta_dev, float eps,
-                               int M, int N, int K, int precision, void* stream) {
-    if (!a_dev || !w_dev || !residual_dev || !out_f32_dev || !out_16_dev || !gamma_dev || !beta_dev)
-        return fail("wm_op_gemm16_ln: null buffer");
-    const int r = launch_gemm16_ln(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, bias_dev, residual_dev, out_f32_dev, out_16_dev,
-                                   gamma_dev, beta_dev, eps, M, N, K);
-    if (r == 1) return fail("wm_op_gemm16_ln: M=%d N=%d K=%d cannot be fused (M %% 256, N %% 320 or 256, <= 8 column tiles, row blocks co-resident)", M, N, K);
-    if (r) return r;
-    return ln_fuse_check(nullptr, (hipStream_t)stream);
-}
-
 extern "C" int wm_op_gemm8(const void* a_dev, const void* w_dev, const float* wscale_dev, const float* bias_dev, const float* residual_dev,
                            float* out_f32_dev, void* out_16_dev, void* out_8_dev, int M, int N, int K, int act, int precision, void* stream) {
     return launch_gemm8(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, wscale_dev, bias_dev, residual_dev, out_f32_dev, out_16_dev, out_8_dev,
@@ -2048,7 +1882,7 @@ extern "C" int wm_op_layernorm(const float* x_dev, const float* gamma_dev, const
                                void* out_16_dev, int64_t rows, int C, int precision, void* stream) {
     const int packed = (precision & WM_LAYOUT_PACKED) != 0;
     precision &= ~WM_LAYOUT_PACKED;
-    if (!out_f32_dev && out_16_dev)      // the transformer blocks' form: column-tiled statistics (bit-identical to wm_op_gemm16_ln)
+    if (!out_f32_dev && out_16_dev)      // the transformer blocks' form: column-tiled statistics (the arithmetic of the folded LayerNorm's statistics)
         return launch_layernorm_block(nullptr, (hipStream_t)stream, precision, x_dev, gamma_dev, beta_dev, eps, out_16_dev, rows, C, packed);
     if (packed) return fail("wm_op_layernorm: the LDS-image-order output exists for the 16-bit-only form");
     return launch_layernorm(nullptr, (hipStream_t)stream, precision, x_dev, gamma_dev, beta_dev, eps, out_f32_dev, out_16_dev, rows, C);

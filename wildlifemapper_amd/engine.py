@@ -32,7 +32,6 @@ class EngineHub:
         if self.precision not in N.PREC_BY_NAME:
             raise ValueError(f"unknown precision {self.precision!r} (bf16 | fp16 | fp8)")
         self.max_batch = int(max_batch or os.environ.get("WM_MAX_BATCH", 0) or 0)
-        self.fuse_ln = os.environ.get("WM_LN_FUSE", "0") == "1"    # wm_config.flags & WM_CFG_FUSE_LN; set before the first forward
         # folded LayerNorm (wm_config.flags & WM_CFG_FOLD_LN): True (default; WM_LN_FOLD=0 turns it off) = the fp16-operand blocks,
         # "all" (WM_LN_FOLD=2) = bf16-operand blocks too; set before the first forward
         self.fold_ln = {"0": False, "2": "all"}.get(os.environ.get("WM_LN_FOLD", "1"), True)
@@ -100,7 +99,7 @@ class EngineHub:
         self.max_batch = max(self.max_batch, batch)
         cfg.max_batch = self.max_batch
         cfg.precision = N.PREC_BY_NAME[self.precision]
-        cfg.flags = (N.CFG_FUSE_LN if self.fuse_ln else 0) | (N.CFG_FOLD_LN if self.fold_ln else 0) | (N.CFG_FOLD_LN_BF16 if self.fold_ln == "all" else 0)
+        cfg.flags = (N.CFG_FOLD_LN if self.fold_ln else 0) | (N.CFG_FOLD_LN_BF16 if self.fold_ln == "all" else 0)
         cfg.fp8_gemms = self.fp8_gemms
         h = C.c_void_p()
         idx = device.index if device.index is not None else torch.cuda.current_device()
