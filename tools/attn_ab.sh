@@ -1,0 +1,11 @@
+#!/bin/bash
+# Dev: time the global attention of several library builds on ONE box, two rounds.  usage: tools/attn_ab.sh <outdir> <lib|-> ...
+O=gpurun_out/$1; shift; mkdir -p $O
+for round in 1 2; do
+  for lib in "$@"; do
+    if [ "$lib" = "-" ]; then r=$(python tools/attn_bench.py --batch 16 --prec fp16 2>&1 | grep global);
+    elif [ "$lib" = "old" ]; then r=$(WM_ATTN_4WAVE=1 python tools/attn_bench.py --batch 16 --prec fp16 2>&1 | grep global);
+    else r=$(WM_HIP_LIB=build/ab/libwm_$lib.so python tools/attn_bench.py --batch 16 --prec fp16 2>&1 | grep global); fi
+    echo "$lib round $round: $r" | tee -a $O/ab.txt
+  done
+done

@@ -26,6 +26,10 @@
 #pragma once
 #include "wm_common.h"
 
+#ifndef WM_DEV_TIMELINE
+#define WM_DEV_TIMELINE 0
+#endif
+
 namespace wm {
 
 struct AttnArgs {
@@ -38,6 +42,9 @@ struct AttnArgs {
     const float* qkv_bias;                          // window kernel: [3*D] fp32 (padded tokens)
     int heads;
     unsigned char* out8;                            // WM_PREC_FP8: write the output as e4m3 bytes (row stride out_stride bytes) instead of 16-bit
+#if WM_DEV_TIMELINE
+    unsigned long long* tl;                         // dev build: s_memtime stamps of workgroup 0 ([wave][64]) or null
+#endif
 };
 
 template <int HD> struct AttnGeom {

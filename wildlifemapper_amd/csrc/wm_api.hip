@@ -18,6 +18,7 @@
 
 #include "../../include/wm_hip.h"
 #include "attn16.h"
+#include "attn_glob8.h"
 #include "dec_kernels.h"
 #include "fft_kernels.h"
 #include "gemm16.h"
@@ -655,6 +656,42 @@ int launch_layernorm_block(wm_handle* h, hipStream_t s, int prec, const float* x
 
 template <class T16, int HD, bool REL>
 int launch_attn_global_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int batch, int kclass) {
+    // the 8-wave anti-phase kernel (attn_glob8.h); WM_ATTN_4WAVE=1 (read once per process; A/B runs) keeps every shape on the 4-wave one
+    static const bool four_wave = getenv("WM_ATTN_4WAVE") && atoi(getenv("WM_ATTN_4WAVE")) != 0;
+    if constexpr (HD <= 80)
+    if (a.nq % 256 == 0 && a.nk >= 128 && !four_wave) {
+        using L8 = Global8Lds<HD, REL>;
+        WM_TRY(set_max_lds((const void*)attn_global8_kernel<T16, HD, REL>, L8::TOTAL + (WM_DEV_TIMELINE ? 4096 : 0)));
+        Bracket br(h, s, kclass, 4.0 * batch * a.heads * (double)a.nq * a.nk * HD, 0.0);
+#if WM_DEV_TIMELINE
+        static const bool dbg = getenv("WM_ATTN_DBG") != nullptr;          // dev: phase stamps of workgroup 0 on the 5th launch
+        static int dbg_count = 0;
+        if (dbg && ++dbg_count == 5) {
+            unsigned long long* buf = nullptr;
+            HIP_TRY(hipMalloc((void**)&buf, 8 * 64 * 8));
+            HIP_TRY(hipMemset(buf, 0, 8 * 64 * 8));
+            AttnArgs a2 = a; a2.tl = buf;
+            hipLaunchKernelGGL((attn_global8_kernel<T16, HD, REL>), dim3(a.nq / 256, a.heads, batch), dim3(512), L8::TOTAL + 4096, s, a2);
+            HIP_TRY(hipStreamSynchronize(s));
+            unsigned long long host[8 * 64];
+            HIP_TRY(hipMemcpy(host, buf, sizeof(host), hipMemcpyDeviceToHost));
+            const unsigned long long t0 = host[0];
+            for (int w = 0; w < 8; ++w) {
+                fprintf(stderr, "g8 wave %d:", w);
+                for (int i = 0; i < 64; ++i) fprintf(stderr, " %lld", (long long)(host[w * 64 + i] - t0));
+                fprintf(stderr, "\n");
+            }
+            hipFree(buf);
+            return 0;
+        }
+        AttnArgs a1 = a; a1.tl = nullptr;
+        hipLaunchKernelGGL((attn_global8_kernel<T16, HD, REL>), dim3(a.nq / 256, a.heads, batch), dim3(512), L8::TOTAL + 4096, s, a1);
+#else
+        hipLaunchKernelGGL((attn_global8_kernel<T16, HD, REL>), dim3(a.nq / 256, a.heads, batch), dim3(512), L8::TOTAL, s, a);
+#endif
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     using L = GlobalLds<HD, REL>;
     WM_TRY(set_max_lds((const void*)attn_global_kernel<T16, HD, REL>, L::TOTAL));
     Bracket br(h, s, kclass, 4.0 * batch * a.heads * (double)a.nq * a.nk * HD, 0.0);
