@@ -40,6 +40,7 @@ struct AttnArgs {
     float scale;                                    // head_dim^-0.5
     const float* rel_h; const float* rel_w;         // [2*S-1, HD] fp32 or null
     const float* qkv_bias;                          // window kernel: [3*D] fp32 (padded tokens)
+    const u16* qkv_bias16;                          // the same, rounded to the operand type: a padded token's K / V row
     int heads;
     unsigned char* out8;                            // WM_PREC_FP8: write the output as e4m3 bytes (row stride out_stride bytes) instead of 16-bit
 #if WM_DEV_TIMELINE
@@ -214,6 +215,43 @@ __device__ __forceinline__ void store_out(SoftmaxState<AttnGeom<HD>::NDT>& st, u
                 }
             }
         }
+}
+
+// The same through a per-wave LDS image [32 queries][ROW_STRIDE bytes]: normalised 16-bit rows are written as the accumulators hold
+// them (8 B per lane, one query per lane) and leave as 16-B chunks of whole rows, `row_ptr(r)` giving query r's output row or null.
+// A row-per-lane store instruction touches 32 different 128-B lines (20 such stores per item: ~3.4k cycles of an 18k-cycle window
+// item in the timeline); a chunked one touches ~8.
+template <class T, int HD, class RowPtr>
+__device__ __forceinline__ void store_out_rows(SoftmaxState<AttnGeom<HD>::NDT>& st, char* stage, int lane, RowPtr row_ptr) {
+    using G = AttnGeom<HD>;
+    constexpr int RS = HD * 2 + 16;
+    const int c = lane & 31, h = lane >> 5;
+    float l;
+    if constexpr (G::LSUM_IN_O) l = __shfl(st.o[G::NDT - 1][G::LSUM_R], c, 64);
+    else l = st.l + __shfl_xor(st.l, 32, 64);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int dt = 0; dt < G::NDT; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int d = 32 * dt + 8 * rg + 4 * h;
+            if (d < HD) {
+                typename T::vec4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = T::from_f32_bounded(st.o[dt][4 * rg + j] * inv);     // a convex combination of V rows
+                *(typename T::vec4*)(stage + c * RS + d * 2) = o;
+            }
+        }
+    constexpr int CH = HD / 8, NCHUNK = 32 * CH;
+#pragma unroll
+    for (int i = 0; i < (NCHUNK + 63) / 64; ++i) {
+        const int e = lane + 64 * i;
+        if (e < NCHUNK) {
+            const int r = e / CH, ch = e % CH;
+            u16* dst = row_ptr(r);
+            if (dst) *(s16x8*)(dst + ch * 8) = *(const s16x8*)(stage + r * RS + ch * 16);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -470,28 +508,23 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
         decode(item, b, win, head);
         const int wy = win / NWIN, wx = win % NWIN;
         const u16* base = p.q + ((size_t)b * GRID * GRID) * p.q_stride + head * HD;   // packed qkv: q +0, k +D, v +2D
+        // the chunk coordinates are re-derived per item from an opaque copy of tid: hoisted out of the item loop they were spilled, and
+        // every reload (scratch = vector memory) came with a vmcnt(0) that drained the prefetch loads issued before it
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            const int e = tid + i * NTHR;
+            const int e = tid_o + i * NTHR;
             const int key = e / G::CH, ch = e % G::CH;                                  // key slot = 16 kh + kw (kw 14, 15: zero rows)
             s16x8 kv8 = s16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv8 = kv8;
             if ((key & 15) < WS) {
+                // a token outside the image is zero after norm1, so its qkv row is the bias (image_encoder.py:190-194, 281): the row
+                // pointer is SELECTED, not branched on -- converting the fp32 bias here put 4 loads and a vmcnt(0) in the middle of
+                // every edge window's prefetch (timeline: 3-9k of an item's 23k cycles went into issuing it)
                 const int y = wy * WS + (key >> 4), x = wx * WS + (key & 15);
-                if (y < GRID && x < GRID) {
-                    const u16* row = base + (size_t)(y * GRID + x) * p.q_stride;
-                    kv8 = *(const s16x8*)(row + D + ch * 8);
-                    vv8 = *(const s16x8*)(row + 2 * D + ch * 8);
-                } else {
-                    // zero-padded token after norm1 -> qkv = bias (image_encoder.py:190-194, 281)
-                    typename T::vec8 tk, tv;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        tk[j] = T::from_f32(p.qkv_bias[D + head * HD + ch * 8 + j]);
-                        tv[j] = T::from_f32(p.qkv_bias[2 * D + head * HD + ch * 8 + j]);
-                    }
-                    kv8 = __builtin_bit_cast(s16x8, tk);
-                    vv8 = __builtin_bit_cast(s16x8, tv);
-                }
+                const u16* row = (y < GRID && x < GRID) ? base + (size_t)(y * GRID + x) * p.q_stride : p.qkv_bias16 + head * HD;
+                kv8 = *(const s16x8*)(row + D + ch * 8);
+                vv8 = *(const s16x8*)(row + 2 * D + ch * 8);
             }
             kreg[i] = kv8;
             vreg[i] = vv8;
@@ -518,6 +551,8 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
         const size_t tok = valid ? (size_t)(y * GRID + x) : 0;
         return QInfo{valid, (size_t)b * GRID * GRID + tok};
     };
+    // (Fetching Q as 16-B chunks of whole rows -- ~14 lines per load instruction instead of 32 -- and forming the fragments through
+    // LDS was tried: the five divisions per lane and the LDS round trip cost more than the lines saved, +4 % per launch.)
     auto load_q = [&](typename T::vec8 (&qf)[G::NKS], int item) {
         int b, win, head;
         decode(item, b, win, head);
@@ -546,16 +581,34 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
     prefetch_kv(item);
     load_q(qf, item);
     commit_kv();
+#pragma unroll
+    for (int ks = 0; ks < G::NKS; ++ks) asm volatile("" : "+v"(qf[ks]));      // landed before the loop, as at its back edge (below)
     v_pad_ones<T, HD>(sV, L::NKEY, tid, NTHR);            // the staging never touches the pad columns again
     __syncthreads();
 
+#if WM_DEV_TIMELINE
+    // dev: stamps of workgroup 0 (items 1..3 of its walk), 16 per item: 0 top, 1 prefetch issued, 2 rel-pos U / V ready, 3..6 key steps,
+    // 7 stored, 8 barrier, 9 K / V committed, 10 barrier
+    unsigned long long* tls = (unsigned long long*)(smem + L::TOTAL) + wave * 64;
+    const bool tl_on = p.tl && blockIdx.x == 0;
+    int tl_it = 0;
+    auto stamp = [&](int k) {
+        if (tl_on && tl_it >= 1 && tl_it < 4) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            if (lane == 0) tls[(tl_it - 1) * 16 + k] = t;
+        }
+    };
+#define WM_WIN_STAMP(k) stamp(k)
+#else
+#define WM_WIN_STAMP(k)
+#endif
     while (true) {
         const int next = item + Gd;
         const bool has_next = next < nitems;
-        if (has_next) {                                   // in flight during this item's compute
-            prefetch_kv(next);
-            load_q(qn, next);
-        }
+        WM_WIN_STAMP(0);
+        if (has_next) prefetch_kv(next);                  // in flight during this item's compute
+        WM_WIN_STAMP(1);
         // T[c][i]: i<32 -> q.rel_h[i], i>=32 -> q.rel_w[i-32], pre-divided by the softmax scale
         float U[WS], V[WS];
         {
@@ -579,6 +632,7 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
                 V[k] = sT[c * 65 + 32 + (qw - k + WS - 1)];
             }
         }
+        WM_WIN_STAMP(2);
         SoftmaxState<G::NDT> st;
         st.init();
         // Key slots are laid out 14 rows (kh) x 16 columns (kw; 14 and 15 are zero rows, masked through the bias): a 32-key MFMA
@@ -601,6 +655,7 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
                 for (int r = 0; r < 16; ++r) s[t][r] = U[4 * j + 2 * t + (r >> 3)] + Vsel[(r & 3) + 4 * ((r >> 2) & 1)];
             qk_tile<T, HD, 2>(s, qf, sK + j * 64 * G::KS, lane);
             softmax_pv<T, HD, 2>(st, s, c1, 0.f, 64, sV + j * 64 * G::VS, lane);
+            WM_WIN_STAMP(3 + j);
         }
         {
             f32x16 s[1];
@@ -612,19 +667,46 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
         {
             int b, win, head;
             decode(item, b, win, head);
-            const QInfo qo = q_info(item);
-            u16* orow = p.out + qo.row * p.out_stride + head * HD;
-            unsigned char* orow8 = p.out8 ? p.out8 + qo.row * p.out_stride + head * HD : nullptr;
-            store_out<T, HD>(st, orow, lane, qo.valid, orow8);
+            WM_WIN_STAMP(6);
+            // the next item's Q fragments: requested here, where the score / P / bias registers are dead (beside the K / V staging
+            // registers they cost 4 spills, and each spill reload's vmcnt(0) serialised the prefetch: timeline), landed by the commit
+            if (has_next) load_q(qn, next);
+            if (p.out8) {
+                const QInfo qo = q_info(item);
+                store_out<T, HD>(st, p.out + qo.row * p.out_stride + head * HD, lane, qo.valid, p.out8 + qo.row * p.out_stride + head * HD);
+            } else {
+                const int wy = win / NWIN, wx = win % NWIN;
+                store_out_rows<T, HD>(st, (char*)sT, lane, [&](int r) -> u16* {
+                    const int slot = wave * 32 + r;
+                    const int sh = slot / WS, sw = slot - sh * WS;
+                    const int y = wy * WS + sh, x = wx * WS + sw;
+                    const bool ok = slot < NTOK && y < GRID && x < GRID;
+                    return ok ? p.out + ((size_t)b * GRID * GRID + (size_t)(y * GRID + x)) * p.out_stride + head * HD : nullptr;
+                });
+            }
         }
+        WM_WIN_STAMP(7);
         if (!has_next) break;
         __syncthreads();                                  // every wave is done with this item's K / V
+        WM_WIN_STAMP(8);
         commit_kv();
+        WM_WIN_STAMP(9);
+        // the Q fragments must have LANDED here: left to hipcc, their vmcnt wait sits at the first MFMA of the next item, behind that
+        // item's K / V prefetch in the in-order counter -- the whole prefetch latency exposed at every item start (timeline: 3-4k cycles)
 #pragma unroll
-        for (int ks = 0; ks < G::NKS; ++ks) qf[ks] = qn[ks];
+        for (int ks = 0; ks < G::NKS; ++ks) { qf[ks] = qn[ks]; asm volatile("" : "+v"(qf[ks])); }
         item = next;
         __syncthreads();
+        WM_WIN_STAMP(10);
+#if WM_DEV_TIMELINE
+        ++tl_it;
+#endif
     }
+#if WM_DEV_TIMELINE
+    __syncthreads();
+    if (tl_on && lane == 0)
+        for (int i = 0; i < 64; ++i) p.tl[wave * 64 + i] = tls[i];
+#endif
 }
 
 }  // namespace wm

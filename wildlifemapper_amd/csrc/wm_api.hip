@@ -227,6 +227,7 @@ struct wm_handle {
     std::map<std::string, float*> w32;
     std::vector<void*> allocs;
     Profiler prof;
+    std::map<std::pair<const float*, int>, uint16_t*> bias16;   // qkv biases rounded to a 16-bit operand type (window attention's padded tokens), by (fp32 copy, type)
     bool row_major = false;                 // WM_ROW_MAJOR_OPERANDS=1 (A/B runs): no operand in LDS-image order
     bool sat_on = false;                    // wm_debug_saturation_enable
     unsigned long long* sat_counts = nullptr;   // [WM_SAT_COUNT] device counters
@@ -718,9 +719,32 @@ int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
     const int nitems = 25 * a.heads * batch;
     const int grid = nitems < num_cu ? nitems : num_cu;
     using L = WindowLds<HD>;
-    WM_TRY(set_max_lds((const void*)attn_window_kernel<T16, HD>, L::TOTAL));
+    WM_TRY(set_max_lds((const void*)attn_window_kernel<T16, HD>, L::TOTAL + (WM_DEV_TIMELINE ? 4096 : 0)));
     Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);   // useful work only
+#if WM_DEV_TIMELINE
+    static const bool dbg = getenv("WM_ATTN_DBG") != nullptr;          // dev: phase stamps of workgroup 0 on the 5th launch
+    static int dbg_count = 0;
+    if (dbg && ++dbg_count == 5) {
+        unsigned long long* buf = nullptr;
+        HIP_TRY(hipMalloc((void**)&buf, 8 * 64 * 8));
+        HIP_TRY(hipMemset(buf, 0, 8 * 64 * 8));
+        AttnArgs a2 = a; a2.tl = buf;
+        hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(grid), dim3(448), L::TOTAL + 4096, s, a2, nitems);
+        HIP_TRY(hipStreamSynchronize(s));
+        unsigned long long host[8 * 64];
+        HIP_TRY(hipMemcpy(host, buf, sizeof(host), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 7; ++w) {
+            fprintf(stderr, "win wave %d:", w);
+            for (int i = 0; i < 48; ++i) fprintf(stderr, " %lld", (long long)(host[w * 64 + i] - host[0]));
+            fprintf(stderr, "\n");
+        }
+        hipFree(buf);
+        return 0;
+    }
+    hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(grid), dim3(448), L::TOTAL + 4096, s, a, nitems);
+#else
     hipLaunchKernelGGL((attn_window_kernel<T16, HD>), dim3(grid), dim3(448), L::TOTAL, s, a, nitems);
+#endif
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -742,6 +766,26 @@ int launch_encoder_attention(wm_handle* h, hipStream_t s, int prec, const void* 
                                     : launch_attn_global_p<BF16>(h, s, a, batch, hd, true, WM_KCLASS_ATTN_GLOBAL);
     }
     if (window != 14) return fail("attention: window=%d unsupported (14 or 0)", window);
+    {   // the bias as a 16-bit row (AttnArgs::qkv_bias16): cached per handle, converted per call without one
+        static uint16_t* op_buf = nullptr;
+        static int op_cap = 0;
+        uint16_t* b16 = nullptr;
+        bool convert = true;
+        if (h) {
+            auto it = h->bias16.find({qkv_bias, prec});
+            if (it != h->bias16.end()) { b16 = it->second; convert = false; }
+            else { WM_TRY(dalloc(h, &b16, (size_t)3 * D * 2)); h->bias16[{qkv_bias, prec}] = b16; }
+        } else {
+            if (op_cap < 3 * D) { if (op_buf) hipFree(op_buf); HIP_TRY(hipMalloc((void**)&op_buf, (size_t)3 * D * 2)); op_cap = 3 * D; }
+            b16 = op_buf;
+        }
+        if (convert) {
+            if (prec == WM_PREC_FP16) hipLaunchKernelGGL(cvt_f32_to_16_kernel<FP16>, dim3((3 * D / 4 + 255) / 256), dim3(256), 0, s, qkv_bias, (u16*)b16, (int64_t)(3 * D / 4));
+            else hipLaunchKernelGGL(cvt_f32_to_16_kernel<BF16>, dim3((3 * D / 4 + 255) / 256), dim3(256), 0, s, qkv_bias, (u16*)b16, (int64_t)(3 * D / 4));
+            HIP_TRY(hipGetLastError());
+        }
+        a.qkv_bias16 = (const u16*)b16;
+    }
     if (hd == 80) return prec == WM_PREC_FP16 ? launch_attn_window_t<FP16, 80>(h, s, a, batch) : launch_attn_window_t<BF16, 80>(h, s, a, batch);
     if (hd == 64) return prec == WM_PREC_FP16 ? launch_attn_window_t<FP16, 64>(h, s, a, batch) : launch_attn_window_t<BF16, 64>(h, s, a, batch);
     return fail("attention: head_dim=%d not built for windows (64, 80)", hd);
@@ -1102,6 +1146,9 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
         auto isc = h->w32.find(kv.first + ".wscale");
         if (isc != h->w32.end()) { hipFree(isc->second); for (auto& a : h->allocs) if (a == isc->second) a = nullptr; h->w32.erase(isc); }
     }
+    // 16-bit copies of the qkv biases are keyed by the fp32 copy's address: a re-upload may reuse an address for new values
+    for (auto& kv : h->bias16) { hipFree(kv.second); for (auto& a : h->allocs) if (a == kv.second) a = nullptr; }
+    h->bias16.clear();
     const int D = h->D;
     for (auto& kv : h->staged) {
         const std::string& name = kv.first;
