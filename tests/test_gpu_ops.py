@@ -521,6 +521,43 @@ def test_global_attention_forces_rescale():
     assert (out.float()[100] - ref[100]).abs().max().item() < 0.05
 
 
+_ATTN_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import gpu_util as G
+torch.manual_seed(11)
+dev = G.dev()
+for prec, hd, rel in (("fp16", 80, True), ("bf16", 64, True), ("fp16", 80, False)):
+    heads, B = 2, 2
+    D = heads * hd
+    x = torch.randn(B * 4096, 3 * D, device=dev) * 0.5
+    x[3000, D:2 * D] = x[100, 0:D] * 40                     # a late running-max jump: the deferred-rescale branch
+    qkv = G.to16(x, prec)
+    if rel:
+        out = G.encoder_attention(qkv, torch.zeros(3 * D, device=dev), torch.randn(127, hd, device=dev) * 0.3,
+                                  torch.randn(127, hd, device=dev) * 0.3, B, heads, hd, 0, prec)
+    else:
+        out = G.mha16(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, heads, hd, 4096, 4096, prec)
+    torch.cuda.synchronize()
+    print(prec, hd, rel, out.view(torch.int16).to(torch.int64).sum().item(), out.view(torch.int16)[::997].flatten()[:64].tolist())
+"""
+
+
+def test_global_attention_8wave_bit_identical_to_4wave():
+    """attn_global8_kernel (8 waves, SIMD partners in anti-phase, LDS-DMA staging) keeps attn_global_kernel's arithmetic per
+    query: the same inputs through both kernels give the same bits.  The A/B switch WM_ATTN_4WAVE is read once per process, so
+    each arm runs in a child process."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for four_wave in ("0", "1"):
+        env = dict(os.environ, WM_ATTN_4WAVE=four_wave)
+        r = subprocess.run([sys.executable, "-c", _ATTN_CHILD, root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l[:4] in ("fp16", "bf16")])
+    assert len(outs[0]) == 3 and outs[0] == outs[1]
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 def test_mha16_hfc_shape(prec):
     """HFC cross-attention geometry: 8 heads x 128, q from one buffer, k/v interleaved in another."""

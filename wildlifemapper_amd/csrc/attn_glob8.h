@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
     const int ntiles = p.nk / 64;
     constexpr int NPK = G::KS / 16, NPV = G::VS / 16, NPIECE = NPK + NPV;
     constexpr int PER = (NPIECE + 7) / 8;
-    static_assert(PER <= 3, "pieces per wave");
+    static_assert(PER <= 5, "pieces per wave");
     struct Piece { bool isv; unsigned long long lanes; unsigned voff; int lds_off; };
     auto piece_setup = [&](int i) {
         Piece d;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
         d.lds_off = (d.isv ? L::K_BYTES : 0) + ql * 1024;
         return d;
     };
-    const Piece pc0 = piece_setup(0), pc1 = piece_setup(1), pc2 = piece_setup(2);
+    const Piece pc0 = piece_setup(0), pc1 = piece_setup(1), pc2 = piece_setup(2), pc3 = piece_setup(3), pc4 = piece_setup(4);
     auto issue1 = [&](const Piece& d, int tile) {
         const char* base = d.isv ? (const char*)vb + (size_t)tile * 128u * (unsigned)p.v_stride
                                  : (const char*)kb + (size_t)tile * 128u * (unsigned)p.k_stride;
@@ -213,6 +213,8 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
         issue1(pc0, tile);
         if constexpr (PER > 1) issue1(pc1, tile);
         if constexpr (PER > 2) issue1(pc2, tile);
+        if constexpr (PER > 3) issue1(pc3, tile);
+        if constexpr (PER > 4) issue1(pc4, tile);
     };
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) v_pad_ones<T, HD>(sKV + sl * L::TILE + L::K_BYTES, 64, tid, 512);
@@ -246,7 +248,6 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
     // covers this wave's LDS latency: all V^T fragments of P V and all K fragments of QK^T are requested up front (hipcc otherwise
     // puts every ds_read directly in front of its MFMA, ~100 cycles of latency per MFMA; measured 2.1x the whole kernel), and the
     // counted lgkmcnt waits hipcc inserts retire them in order under the MFMAs.
-    static_assert(HD <= 80, "schedule written for head_dim <= 80");
     // (pv / qk are compile-time: with run-time flags hipcc joins the three bodies through copies of the O accumulators, 24 v_mov_b64
     // per tile behind s_nop 7 -- seen in the ISA, 48 cycles per MFMA)
     auto m_phase = [&](int j, auto pv_c, auto qk_c) {

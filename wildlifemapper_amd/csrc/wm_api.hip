@@ -659,6 +659,8 @@ template <class T16, int HD, bool REL>
 int launch_attn_global_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int batch, int kclass) {
     // the 8-wave anti-phase kernel (attn_glob8.h); WM_ATTN_4WAVE=1 (read once per process; A/B runs) keeps every shape on the 4-wave one
     static const bool four_wave = getenv("WM_ATTN_4WAVE") && atoi(getenv("WM_ATTN_4WAVE")) != 0;
+    // head_dim 128 (the HFC cross-attention) stays on the 4-wave kernel: 32 MFMAs against the same softmax per key tile leave the two
+    // phases unbalanced, 1227 vs 1189 us
     if constexpr (HD <= 80)
     if (a.nq % 256 == 0 && a.nk >= 128 && !four_wave) {
         using L8 = Global8Lds<HD, REL>;
