@@ -9,7 +9,7 @@ coalesced reads are counted at half their bytes).  Averages are per launch over 
 import collections, csv, glob, json, os, sys
 
 csv.field_size_limit(1 << 30)
-CLASSES = (("gemm16", ("gemm16", "gemm8_kernel")), ("attn_global", ("attn_global_kernel",)), ("attn_window", ("attn_window_kernel",)),
+CLASSES = (("gemm16", ("gemm16", "gemm8_kernel")), ("attn_global", ("attn_global_kernel", "attn_global8_kernel")), ("attn_window", ("attn_window_kernel",)),
            ("layernorm", ("layernorm_kernel",)))
 
 

@@ -13,7 +13,7 @@ rocprofv3 -i tools/pmc_traffic.txt --kernel-trace --output-format csv -d gpurun_
 python3 tools/pmc_summarize.py gpurun_out/pmc_${TAG}_$P gpurun_out/$TAG/${P}_pmc_traffic.json "rocprofv3 -i tools/pmc_traffic.txt --kernel-trace -- python3 bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-roofline" 16 $P > /dev/null
 echo "pmc traffic $P done"
 rocprofv3 -i tools/pmc_util.txt --kernel-trace --output-format csv -d gpurun_out/pmcu_${TAG}_$P -- python3 bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/$TAG/pmcu_$P.log 2>&1
-python3 tools/pmc_kernel.py gpurun_out/pmcu_${TAG}_$P gemm16v5_kernel gemm8_kernel attn_window_kernel attn_global_kernel layernorm_tiled > gpurun_out/$TAG/${P}_pmc_util.txt
+python3 tools/pmc_kernel.py gpurun_out/pmcu_${TAG}_$P gemm16v5_kernel gemm8_kernel attn_window_kernel attn_global8_kernel attn_global_kernel layernorm_tiled > gpurun_out/$TAG/${P}_pmc_util.txt
 echo "pmc util $P done"
 done
 for P in $PRECS; do

@@ -274,8 +274,11 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // 1-D grid, XCD-aware: the workgroups of one (image, head) share K / V and get one XCD's L2 (attn_glob8.h has the measurement)
+    const int nqb = p.nq / 128;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = (lid / nqb) % p.heads, b = lid / (nqb * p.heads);
+    const int q0 = (lid % nqb) * 128 + wave * 32;
     const float c1 = p.scale * 1.44269504088896340736f;
 
     const u16* qb = p.q + ((size_t)b * p.nq) * p.q_stride + head * HD;

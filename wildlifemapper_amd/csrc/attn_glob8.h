@@ -83,8 +83,13 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;                              // SIMD partners are waves w and w + 4 (grouping w, w ^ 1 or w, w ^ 2: 18-20 % slower)
     const int c = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 256 + wave * 32;
+    // 1-D grid, XCD-aware: the nq / 256 workgroups of one (image, head) read the same K / V, so they get consecutive logical ids =
+    // one XCD = one L2 (as a 3-D grid they were dealt round-robin over the 8 XCDs and every L2 fetched every K / V: 1.34 GB of HBM
+    // reads per launch for 0.5 GB of qkv, profiles/r3_final_fp16_pmc_traffic.json before this)
+    const int nqb = p.nq / 256;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = (lid / nqb) % p.heads, b = lid / (nqb * p.heads);
+    const int q0 = (lid % nqb) * 256 + wave * 32;
     const float c1 = p.scale * 1.44269504088896340736f;
 
     const u16* qb = p.q + ((size_t)b * p.nq) * p.q_stride + head * HD;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
     // dev: stamps of workgroup 0, per wave, tiles 4..8, 12 per tile: 0 V start, 1 row max known, 2 P built, 3 staging committed, 4 next loads
     // issued, 5 barrier passed, 6 P V issued, 7 QK^T issued, 8 barrier passed
     unsigned long long* tls = (unsigned long long*)(smem + L::TOTAL) + wave * 64;
-    const bool tl_on = p.tl && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    const bool tl_on = p.tl && blockIdx.x == 0;
     auto stamp = [&](int k, int j) {
         if (tl_on && j >= 4 && j < 9) {
             unsigned long long t;

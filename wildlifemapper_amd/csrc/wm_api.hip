@@ -674,7 +674,7 @@ int launch_attn_global_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
             HIP_TRY(hipMalloc((void**)&buf, 8 * 64 * 8));
             HIP_TRY(hipMemset(buf, 0, 8 * 64 * 8));
             AttnArgs a2 = a; a2.tl = buf;
-            hipLaunchKernelGGL((attn_global8_kernel<T16, HD, REL>), dim3(a.nq / 256, a.heads, batch), dim3(512), L8::TOTAL + 4096, s, a2);
+            hipLaunchKernelGGL((attn_global8_kernel<T16, HD, REL>), dim3((a.nq / 256) * a.heads * batch), dim3(512), L8::TOTAL + 4096, s, a2);
             HIP_TRY(hipStreamSynchronize(s));
             unsigned long long host[8 * 64];
             HIP_TRY(hipMemcpy(host, buf, sizeof(host), hipMemcpyDeviceToHost));
@@ -688,9 +688,9 @@ int launch_attn_global_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
             return 0;
         }
         AttnArgs a1 = a; a1.tl = nullptr;
-        hipLaunchKernelGGL((attn_global8_kernel<T16, HD, REL>), dim3(a.nq / 256, a.heads, batch), dim3(512), L8::TOTAL + 4096, s, a1);
+        hipLaunchKernelGGL((attn_global8_kernel<T16, HD, REL>), dim3((a.nq / 256) * a.heads * batch), dim3(512), L8::TOTAL + 4096, s, a1);
 #else
-        hipLaunchKernelGGL((attn_global8_kernel<T16, HD, REL>), dim3(a.nq / 256, a.heads, batch), dim3(512), L8::TOTAL, s, a);
+        hipLaunchKernelGGL((attn_global8_kernel<T16, HD, REL>), dim3((a.nq / 256) * a.heads * batch), dim3(512), L8::TOTAL, s, a);
 #endif
         HIP_TRY(hipGetLastError());
         return 0;
@@ -698,7 +698,7 @@ int launch_attn_global_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
     using L = GlobalLds<HD, REL>;
     WM_TRY(set_max_lds((const void*)attn_global_kernel<T16, HD, REL>, L::TOTAL));
     Bracket br(h, s, kclass, 4.0 * batch * a.heads * (double)a.nq * a.nk * HD, 0.0);
-    hipLaunchKernelGGL((attn_global_kernel<T16, HD, REL>), dim3(a.nq / 128, a.heads, batch), dim3(256), L::TOTAL, s, a);
+    hipLaunchKernelGGL((attn_global_kernel<T16, HD, REL>), dim3((a.nq / 128) * a.heads * batch), dim3(256), L::TOTAL, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
