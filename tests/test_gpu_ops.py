@@ -582,8 +582,11 @@ def C_off(t, elems):
     return ctypes.c_void_p(t.data_ptr() + elems * t.element_size())
 
 
-@pytest.mark.parametrize("nq,nk,heads,hd", [(51, 4096, 8, 16), (4096, 51, 8, 16), (51, 51, 8, 32), (7, 130, 2, 16)])
+@pytest.mark.parametrize("nq,nk,heads,hd", [(51, 4096, 8, 16), (4096, 51, 8, 16), (51, 51, 8, 32), (7, 130, 2, 16),
+                                            (64, 1024, 2, 16), (1, 2048, 3, 16), (65, 1024, 2, 16), (51, 1100, 2, 16)])
 def test_mha32(nq, nk, heads, hd):
+    """(51, 4096), (64, 1024), (1, 2048): the key-split kernels (keys over workgroups + chunk merge); (65, 1024) and (51, 1100) fall
+    outside their geometry (nq <= 64, nk a multiple of 256) and take the query-group kernel."""
     B, dev = 2, G.dev()
     q = torch.randn(B, nq, heads * hd, device=dev)
     k = torch.randn(B, nk, heads * hd, device=dev)

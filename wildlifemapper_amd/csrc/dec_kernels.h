@@ -96,6 +96,121 @@ __global__ __launch_bounds__(64 * NW) void mha32_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// Few queries over many keys (token -> image, transformer.py:160-170 and :97-104: 51 queries per tile, 4096 keys), keys split
+// over workgroups: mha32_kernel<16, 4, 4> gives every group of 4 queries its own workgroup, so the 512 KB of one (tile, head)'s
+// K / V are read 13 times (165 us per launch at 16 tiles, K / V traffic).  Here a workgroup owns KC consecutive keys of one
+// (tile, head): it reads them ONCE into LDS; lane = query (nq <= 64), the 4 waves take KC / 4 keys each and read every K / V row
+// as an LDS broadcast; the 4 partial softmaxes are merged through LDS and written as (o[HD], m, l) per query and key chunk;
+// mha32_merge_chunks_kernel combines the chunks.  grid (nk / KC, heads, B), 256 threads.
+// ---------------------------------------------------------------------------
+template <int HD, int KC>
+__global__ __launch_bounds__(256) void mha32_keysplit_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v, float* __restrict__ part,
+                                                             int nq, int nk, int heads) {
+    static_assert(KC % 4 == 0 && HD % 4 == 0, "geometry");
+    __shared__ __attribute__((aligned(16))) float sK[KC * HD];
+    __shared__ __attribute__((aligned(16))) float sV[KC * HD];
+    __shared__ float sP[4][64][HD + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z, nchunk = gridDim.x;
+    const int C = heads * HD;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const float* kb = k + ((size_t)b * nk + (size_t)chunk * KC) * C + head * HD;
+    const float* vb = v + ((size_t)b * nk + (size_t)chunk * KC) * C + head * HD;
+    constexpr int CPR = HD / 4;                               // 16-byte chunks per row
+    for (int e = tid; e < KC * CPR; e += 256) {
+        const int row = e / CPR, c4 = e % CPR;
+        *(f32x4*)(sK + row * HD + c4 * 4) = *(const f32x4*)(kb + (size_t)row * C + c4 * 4);
+        *(f32x4*)(sV + row * HD + c4 * 4) = *(const f32x4*)(vb + (size_t)row * C + c4 * 4);
+    }
+    float qv[HD], acc[HD];
+    {
+        const int qi = min(lane, nq - 1);                     // lanes past nq recompute the last query; not stored
+        const float* qp = q + ((size_t)b * nq + qi) * C + head * HD;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const f32x4 t = *(const f32x4*)(qp + d);
+            qv[d] = t[0] * scale; qv[d + 1] = t[1] * scale; qv[d + 2] = t[2] * scale; qv[d + 3] = t[3] * scale;
+        }
+    }
+    float m = -1e30f, l = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+    __syncthreads();
+    constexpr int KW = KC / 4;
+#pragma unroll 2
+    for (int j = 0; j < KW; ++j) {
+        const float* kr = sK + (wave * KW + j) * HD;          // wave-uniform address: an LDS broadcast
+        const float* vr = sV + (wave * KW + j) * HD;
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const f32x4 t = *(const f32x4*)(kr + d);
+            sc = fmaf(qv[d], t[0], sc); sc = fmaf(qv[d + 1], t[1], sc); sc = fmaf(qv[d + 2], t[2], sc); sc = fmaf(qv[d + 3], t[3], sc);
+        }
+        const float mn = fmaxf(m, sc);
+        const float a = expf(m - mn), pe = expf(sc - mn);
+        l = l * a + pe;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const f32x4 u = *(const f32x4*)(vr + d);
+            acc[d] = fmaf(acc[d], a, pe * u[0]); acc[d + 1] = fmaf(acc[d + 1], a, pe * u[1]);
+            acc[d + 2] = fmaf(acc[d + 2], a, pe * u[2]); acc[d + 3] = fmaf(acc[d + 3], a, pe * u[3]);
+        }
+        m = mn;
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) sP[wave][lane][d] = acc[d];
+    sP[wave][lane][HD] = m; sP[wave][lane][HD + 1] = l;
+    __syncthreads();
+    // merge the 4 waves: thread (query, 4-column group) of the first 64 * HD / 4 threads
+    if (tid < 64 * (HD / 4)) {
+        const int qi = tid / (HD / 4), d0 = (tid % (HD / 4)) * 4;
+        if (qi < nq) {
+            float M = sP[0][qi][HD];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) M = fmaxf(M, sP[w][qi][HD]);
+            float L = 0.f;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float f = expf(sP[w][qi][HD] - M);
+                L += sP[w][qi][HD + 1] * f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) o[jj] += sP[w][qi][d0 + jj] * f;
+            }
+            float* dst = part + ((((size_t)b * heads + head) * nchunk + chunk) * 64 + qi) * (HD + 2);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) dst[d0 + jj] = o[jj];
+            if (d0 == 0) { dst[HD] = M; dst[HD + 1] = L; }
+        }
+    }
+}
+
+// out[b][q][head*HD + d] = sum_chunks o f / sum_chunks l f, f = exp(m_chunk - max m).  grid (heads, B), 64 * HD / 4 threads
+template <int HD>
+__global__ void mha32_merge_chunks_kernel(const float* __restrict__ part, float* __restrict__ out, int nq, int nchunk, int heads) {
+    const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int qi = tid / (HD / 4), d0 = (tid % (HD / 4)) * 4;
+    if (qi >= nq) return;
+    const float* src = part + (((size_t)b * heads + head) * nchunk * 64 + qi) * (HD + 2);
+    const size_t cs = (size_t)64 * (HD + 2);
+    float M = -1e30f;
+    for (int c = 0; c < nchunk; ++c) M = fmaxf(M, src[c * cs + HD]);
+    float L = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nchunk; ++c) {
+        const float f = expf(src[c * cs + HD] - M);
+        L += src[c * cs + HD + 1] * f;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) o[jj] += src[c * cs + d0 + jj] * f;
+    }
+    const float inv = 1.0f / L;
+    float* dst = out + ((size_t)b * nq + qi) * (heads * HD) + head * HD + d0;
+    *(f32x4*)dst = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+}
+
+// ---------------------------------------------------------------------------
 // The same attention for many queries over a few keys (image -> token, transformer.py:172-178: 4096 queries per
 // tile, NK = 51 keys).  One THREAD per query: K and V rows are uniform across the wave (scalar loads, operands from
 // SGPRs), the NK scores stay in registers (two-pass softmax, no rescaling), nothing crosses lanes.

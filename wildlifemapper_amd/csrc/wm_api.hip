@@ -228,6 +228,8 @@ struct wm_handle {
     std::vector<void*> allocs;
     Profiler prof;
     std::map<std::pair<const float*, int>, uint16_t*> bias16;   // qkv biases rounded to a 16-bit operand type (window attention's padded tokens), by (fp32 copy, type)
+    float* mha_part = nullptr;              // token -> image attention: per key chunk partial softmaxes (launch_mha32)
+    size_t mha_part_cap = 0;
     bool row_major = false;                 // WM_ROW_MAJOR_OPERANDS=1 (A/B runs): no operand in LDS-image order
     bool sat_on = false;                    // wm_debug_saturation_enable
     unsigned long long* sat_counts = nullptr;   // [WM_SAT_COUNT] device counters
@@ -809,7 +811,26 @@ int launch_mha32(wm_handle* h, hipStream_t s, const float* q, const float* k, co
     // many keys, few queries (token -> image): 4 queries share each K / V row and 4 waves split the keys; otherwise one
     // query per wave
     const bool share = nk >= 1024;
-    if (hd == 16 && nk == NQ && nq >= 1024)       // image -> token: one thread per query, K / V from scalar loads
+    constexpr int KC = 256;                        // keys per workgroup of the key-split kernel
+    if (hd == 16 && nq <= 64 && nk >= 1024 && nk % KC == 0) {
+        // token -> image: keys split over workgroups, K / V read once (dec_kernels.h); partials in a scratch buffer of the handle
+        // (or, for handle-less op calls, of the process)
+        const int nchunk = nk / KC;
+        const size_t need = (size_t)batch * heads * nchunk * 64 * (16 + 2) * 4;
+        static float* op_part = nullptr;
+        static size_t op_cap = 0;
+        float** buf = h ? &h->mha_part : &op_part;
+        size_t* cap = h ? &h->mha_part_cap : &op_cap;
+        if (*cap < need) {
+            if (*buf) { HIP_TRY(hipStreamSynchronize(s)); hipFree(*buf); if (h) for (auto& a : h->allocs) if (a == *buf) a = nullptr; }
+            void* pnew = nullptr;
+            HIP_TRY(hipMalloc(&pnew, need));
+            if (h) h->allocs.push_back(pnew);
+            *buf = (float*)pnew; *cap = need;
+        }
+        hipLaunchKernelGGL((mha32_keysplit_kernel<16, KC>), dim3(nchunk, heads, batch), dim3(256), 0, s, q, k, v, *buf, nq, nk, heads);
+        hipLaunchKernelGGL((mha32_merge_chunks_kernel<16>), dim3(heads, batch), dim3(64 * 4), 0, s, (const float*)*buf, out, nq, nchunk, heads);
+    } else if (hd == 16 && nk == NQ && nq >= 1024)       // image -> token: one thread per query, K / V from scalar loads
         hipLaunchKernelGGL((mha32_fewkeys_kernel<16, NQ>), dim3((nq + 255) / 256, heads, batch), dim3(256), 0, s, q, k, v, out, nq, heads);
     else if (hd == 16 && share) hipLaunchKernelGGL((mha32_kernel<16, 4, 4>), dim3((nq + 3) / 4, heads, batch), dim3(256), 0, s, q, k, v, out, nq, nk, heads);
     else if (hd == 16) hipLaunchKernelGGL((mha32_kernel<16, 1>), dim3(nq, heads, batch), dim3(64), 0, s, q, k, v, out, nq, nk, heads);
