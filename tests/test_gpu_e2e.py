@@ -278,6 +278,34 @@ def test_dropin_modules_and_batch_invariance():
     assert set(res[0]) == {"scores", "labels", "boxes"}
 
 
+def test_partial_weight_reupload_matches_fresh_handle():
+    """A parameter changed in place after the first forward (here a window block's and a global block's qkv bias, plus a LayerNorm
+    gamma) is re-uploaded into the SAME native handle; everything the handle derives from weights -- packed copies, folded LayerNorm
+    weights, the 16-bit qkv-bias rows the window attention reads for padded tokens (cached by device address) -- must follow.  The
+    result has to equal a fresh handle's bit for bit."""
+    m, _ = _model("vit_b", "fp16")
+    x = torch.from_numpy(synth.make_batch(4, 2)).to(G.dev())
+    hub = m._hub
+    first = m(NestedTensor(x, None), None)["pred_logits"].clone()
+    blocks = m.image_encoder.blocks
+    touched = [blocks[0].attn.qkv.bias, blocks[2].attn.qkv.bias, blocks[1].norm1.weight]
+    saved = [t.detach().clone() for t in touched]
+    try:
+        with torch.no_grad():
+            touched[0].add_(0.25); touched[1].mul_(-1.5); touched[2].mul_(1.1)
+        again = m(NestedTensor(x, None), None)["pred_logits"].clone()          # partial re-upload into the live handle
+        assert not torch.equal(again, first)
+        hub.close()                                                             # fresh handle, full upload of the same weights
+        fresh = m(NestedTensor(x, None), None)["pred_logits"].clone()
+        assert torch.equal(again, fresh)
+    finally:
+        with torch.no_grad():
+            for t, s0 in zip(touched, saved): t.copy_(s0)
+        hub.close()
+    restored = m(NestedTensor(x, None), None)["pred_logits"]
+    assert torch.equal(restored, first)
+
+
 def test_folded_layernorm_off_switch_and_tile_independence():
     """WM_LN_FOLD=0 (hub.fold_ln = False) runs the blocks' LayerNorm as its own kernel: both paths meet the reference fixture,
     within each a tile's bits do not depend on its batch neighbours, and the two differ only within the operand rounding."""
