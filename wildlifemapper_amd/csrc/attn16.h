@@ -649,6 +649,100 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
             const int kw0 = (i8 & 3) + 8 * (i8 >> 2);                              // half 0; half 1: + 4
             Vsel[i8] = h ? (kw0 + 4 < WS ? V[kw0 + 4 < WS ? kw0 + 4 : 0] : -1e30f) : V[kw0 < WS ? kw0 : 0];
         }
+#ifndef WM_WIN_PIPELINED
+#define WM_WIN_PIPELINED 1
+#endif
+#if WM_WIN_PIPELINED
+        // Key loop in 7 half-steps of 32 keys (two kh rows), software-pipelined inside the wave: QK^T of half-step i + 1 is ISSUED
+        // before the exponentials of half-step i, so the matrix pipe works under this wave's own softmax (the two waves of a SIMD
+        // overlap only by chance: timeline, 7k cycles of key loop per wave, 14k of a 17k-cycle item on a two-wave SIMD).  Two score
+        // tiles of 16 registers alternate -- the same 32 registers the 64-key step held.
+        {
+            f32x16 sp[2][1];
+            auto s_init = [&](f32x16& d, int i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = U[2 * i + (r >> 3)] + Vsel[(r & 3) + 4 * ((r >> 2) & 1)];
+            };
+            s_init(sp[0][0], 0);
+            qk_tile<T, HD, 1>(sp[0], qf, sK, lane);
+            const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+            const int v_lane_off = (4 * (g >> 1) + lq) * G::VS + (16 * (g & 1) + 4 * lp) * 2;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                f32x16& cur = sp[i & 1][0];
+                float mx = -1e30f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cur[r]);
+                mx *= c1;
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float m_use = st.m;
+                if (!__all(mx - st.m <= RESCALE_THR)) {
+                    const float m_new = fmaxf(st.m, mx);
+                    const float alpha = __builtin_amdgcn_exp2f(st.m - m_new);
+                    st.l *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < G::NDT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
+                    st.m = m_new;
+                    m_use = m_new;
+                }
+                // From here the order is written out and fenced (sched_barrier): left alone, hipcc clusters the 16 exponentials and
+                // puts all 11 MFMAs behind them.  QK^T(i + 1): one MFMA, then three or four scores' exponentials, five times; then
+                // P V(i): one MFMA per ~4 vector instructions (the converts of the second P fragment, the next tile's bias sums).
+                const float off = -m_use;
+                float ls = 0.f;
+                const bool more = i + 1 < 7;
+                f32x16& nxt = sp[(i + 1) & 1][0];
+                const char* kn = sK + (i + 1) * 32 * G::KS + (lane & 31) * G::KS + 16 * h;
+                if (more) s_init(nxt, i + 1);
+                typename T::vec8 kf[G::NKS];                                // K fragments: two requested ahead of their MFMA
+                if (more) { kf[0] = lds_read_v8<T>(kn); kf[1] = lds_read_v8<T>(kn + 32); }
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int EPG = (16 + G::NKS - 1) / G::NKS;             // exponentials per MFMA gap
+#pragma unroll
+                for (int ks = 0; ks < G::NKS; ++ks) {
+                    if (more) {
+                        nxt = T::mfma32(kf[ks], qf[ks], nxt);
+                        if (ks + 2 < G::NKS) kf[ks + 2] = lds_read_v8<T>(kn + 32 * (ks + 2));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = ks * EPG; r < min(16, (ks + 1) * EPG); ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(cur[r], c1, off));
+                        cur[r] = pv;
+                        if constexpr (!G::LSUM_IN_O) ls += pv;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                st.l += ls;
+                typename T::vec8 pb0, pb1;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pb0[jj] = T::from_f32_bounded(cur[jj]);
+                const char* vp = sV + (i * 32) * G::VS + v_lane_off;
+                typename T::vec8 va[G::NDT], vb[G::NDT];                    // V^T fragments of the two 16-key halves
+#pragma unroll
+                for (int dt = 0; dt < G::NDT; ++dt) va[dt] = lds_read_vT<T>(vp + dt * 64, 8 * G::VS);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < G::NDT; ++dt) {
+                    st.o[dt] = T::mfma32(va[dt], pb0, st.o[dt]);
+                    vb[dt] = lds_read_vT<T>(vp + 16 * G::VS + dt * 64, 8 * G::VS);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int jj = dt * 3; jj < min(8, dt * 3 + 3); ++jj) pb1[jj] = T::from_f32_bounded(cur[8 + jj]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (G::NDT * 3 < 8) {
+#pragma unroll
+                    for (int jj = G::NDT * 3; jj < 8; ++jj) pb1[jj] = T::from_f32_bounded(cur[8 + jj]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < G::NDT; ++dt) st.o[dt] = T::mfma32(vb[dt], pb1, st.o[dt]);
+                if (i == 1 || i == 3 || i == 5) WM_WIN_STAMP(3 + i / 2);
+            }
+        }
+#else
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             f32x16 s[2];
@@ -667,6 +761,7 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
             qk_tile<T, HD, 1>(s, qf, sK + 192 * G::KS, lane);
             softmax_pv<T, HD, 1>(st, s, c1, 0.f, 32, sV + 192 * G::VS, lane);
         }
+#endif
         {
             int b, win, head;
             decode(item, b, win, head);
