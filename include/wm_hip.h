@@ -334,6 +334,13 @@ int wm_op_encoder_attention(const void* qkv_dev, const float* qkv_bias_dev,
                             const float* rel_pos_h_dev, const float* rel_pos_w_dev, void* out_dev,
                             int batch, int heads, int head_dim, int window, int precision, void* stream);
 
+/* The same with q, k and v as three [B*4096, >= D] tensors of one token stride (elements): any layout whose heads are
+ * head_dim-wide column groups, e.g. a head-major copy passed as batch = B*heads images of one head
+ * (tools/attn_headmajor_probe.py). */
+int wm_op_encoder_attention_qkv(const void* q_dev, const void* k_dev, const void* v_dev, int token_stride,
+                                const float* qkv_bias_dev, const float* rel_pos_h_dev, const float* rel_pos_w_dev,
+                                void* out_dev, int batch, int heads, int head_dim, int window, int precision, void* stream);
+
 /* Plain multi-head attention softmax(q k^T / sqrt(hd)) v, no bias terms (HFC adaptor,
  * image_encoder.py:500-503).  q [B,Nq,*] row stride q_stride, k/v [B,Nk,*] (16-bit). */
 int wm_op_mha16(const void* q_dev, int q_stride, const void* k_dev, int k_stride,

@@ -87,6 +87,7 @@ SYMBOLS = {
     "wm_op_gemm32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "wm_op_layernorm": (_I, [_P, _P, _P, _F, _P, _P, _L, _I, _I, _P]),
     "wm_op_encoder_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm_op_encoder_attention_qkv": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm_op_mha16": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "wm_op_mha32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
 }

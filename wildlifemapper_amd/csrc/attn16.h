@@ -510,7 +510,8 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
         int b, win, head;
         decode(item, b, win, head);
         const int wy = win / NWIN, wx = win % NWIN;
-        const u16* base = p.q + ((size_t)b * GRID * GRID) * p.q_stride + head * HD;   // packed qkv: q +0, k +D, v +2D
+        const u16* kbase = p.k + ((size_t)b * GRID * GRID) * p.k_stride + head * HD;
+        const u16* vbase = p.v + ((size_t)b * GRID * GRID) * p.v_stride + head * HD;
         // the chunk coordinates are re-derived per item from an opaque copy of tid: hoisted out of the item loop they were spilled, and
         // every reload (scratch = vector memory) came with a vmcnt(0) that drained the prefetch loads issued before it
         int tid_o = tid;
@@ -525,9 +526,10 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
                 // pointer is SELECTED, not branched on -- converting the fp32 bias here put 4 loads and a vmcnt(0) in the middle of
                 // every edge window's prefetch (timeline: 3-9k of an item's 23k cycles went into issuing it)
                 const int y = wy * WS + (key >> 4), x = wx * WS + (key & 15);
-                const u16* row = (y < GRID && x < GRID) ? base + (size_t)(y * GRID + x) * p.q_stride : p.qkv_bias16 + head * HD;
-                kv8 = *(const s16x8*)(row + D + ch * 8);
-                vv8 = *(const s16x8*)(row + 2 * D + ch * 8);
+                const bool in = y < GRID && x < GRID;
+                const size_t tok = (size_t)(y * GRID + x);
+                kv8 = *(const s16x8*)((in ? kbase + tok * p.k_stride : p.qkv_bias16 + D + head * HD) + ch * 8);
+                vv8 = *(const s16x8*)((in ? vbase + tok * p.v_stride : p.qkv_bias16 + 2 * D + head * HD) + ch * 8);
             }
             kreg[i] = kv8;
             vreg[i] = vv8;

@@ -754,13 +754,15 @@ int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
 }
 
 int launch_encoder_attention(wm_handle* h, hipStream_t s, int prec, const void* qkv, const float* qkv_bias,
-                             const float* rel_h, const float* rel_w, void* out, int batch, int heads, int hd, int window, void* out8 = nullptr) {
+                             const float* rel_h, const float* rel_w, void* out, int batch, int heads, int hd, int window, void* out8 = nullptr,
+                             const void* k_sep = nullptr, const void* v_sep = nullptr, int tok_stride = 0) {
     const int D = heads * hd;
     AttnArgs a{};
     a.out8 = (unsigned char*)out8;
     a.q = (const u16*)qkv; a.k = (const u16*)qkv + D; a.v = (const u16*)qkv + 2 * D;
     a.out = (u16*)out;
     a.q_stride = a.k_stride = a.v_stride = 3 * D;
+    if (k_sep) { a.k = (const u16*)k_sep; a.v = (const u16*)v_sep; a.q_stride = a.k_stride = a.v_stride = tok_stride; }   // q / k / v as three tensors
     a.out_stride = D;
     a.nq = a.nk = T;
     a.scale = 1.0f / sqrtf((float)hd);
@@ -2000,6 +2002,13 @@ extern "C" int wm_op_encoder_attention(const void* qkv_dev, const float* qkv_bia
                                        int precision, void* stream) {
     return launch_encoder_attention(nullptr, (hipStream_t)stream, precision, qkv_dev, qkv_bias_dev, rel_pos_h_dev, rel_pos_w_dev, out_dev,
                                     batch, heads, head_dim, window);
+}
+
+extern "C" int wm_op_encoder_attention_qkv(const void* q_dev, const void* k_dev, const void* v_dev, int token_stride, const float* qkv_bias_dev,
+                                           const float* rel_pos_h_dev, const float* rel_pos_w_dev, void* out_dev, int batch, int heads,
+                                           int head_dim, int window, int precision, void* stream) {
+    return launch_encoder_attention(nullptr, (hipStream_t)stream, precision, q_dev, qkv_bias_dev, rel_pos_h_dev, rel_pos_w_dev, out_dev,
+                                    batch, heads, head_dim, window, nullptr, k_dev, v_dev, token_stride);
 }
 
 extern "C" int wm_op_mha16(const void* q_dev, int q_stride, const void* k_dev, int k_stride, const void* v_dev, int v_stride,
