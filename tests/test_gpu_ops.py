@@ -521,6 +521,32 @@ def test_global_attention_forces_rescale():
     assert (out.float()[100] - ref[100]).abs().max().item() < 0.05
 
 
+@pytest.mark.parametrize("window", [14, 0])
+def test_encoder_attention_qkv_three_tensors(window):
+    """wm_op_encoder_attention_qkv: q / k / v as three tensors of one token stride.  Fed with per-head contiguous copies (each
+    (image, head) as an image of one head) it must give the packed-qkv entry point's bits for that head."""
+    B, heads, hd, prec = 2, 3, 80, "fp16"
+    D, dev = heads * hd, G.dev()
+    torch.manual_seed(5)
+    qkv = G.to16(torch.randn(B * 4096, 3 * D, device=dev) * 0.5, prec)
+    bias = torch.randn(3 * D, device=dev) * 0.1
+    S = 14 if window else 64
+    rel_h = torch.randn(2 * S - 1, hd, device=dev) * 0.2
+    rel_w = torch.randn(2 * S - 1, hd, device=dev) * 0.2
+    ref = G.encoder_attention(qkv, bias, rel_h, rel_w, B, heads, hd, window, prec).view(B, 4096, heads, hd)
+    def per_head(x):
+        return x.reshape(B, 4096, heads, hd).permute(0, 2, 1, 3).contiguous().view(B * heads * 4096, hd)
+    q, k, v = per_head(qkv[:, :D]), per_head(qkv[:, D:2 * D]), per_head(qkv[:, 2 * D:])
+    for head in range(heads):
+        b1 = torch.cat([bias[head * hd:(head + 1) * hd], bias[D + head * hd:D + (head + 1) * hd],
+                        bias[2 * D + head * hd:2 * D + (head + 1) * hd]]).contiguous()
+        out = torch.empty(B * heads * 4096, hd, device=dev, dtype=torch.float16)
+        N = G.N
+        N.check(N.lib().wm_op_encoder_attention_qkv(N.ptr(q), N.ptr(k), N.ptr(v), hd, N.ptr(b1), N.ptr(rel_h), N.ptr(rel_w), N.ptr(out),
+                                                    B * heads, 1, hd, window, G.PRECS[prec][0], G.sp()))
+        assert torch.equal(out.view(B, heads, 4096, hd)[:, head], ref[:, :, head])
+
+
 _ATTN_CHILD = r"""
 import sys, torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
