@@ -410,6 +410,28 @@ def main() -> None:
                         break
             except Exception:
                 traffic = None
+            # north_star: "rocprof-reported MFMA utilisation and HBM GB/s against gfx950 peak" for the dominant kernel.  HBM GB/s = the
+            # committed PMC bytes per launch / the live HIP-event launch time; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x
+            # 128 SIMDs per XCD) from the committed counter pass of the same workload (profiles/<round>_pmc_util.txt).
+            avg_launch_s = g["ms"] * 1e-3 / max(g["launches"], 1)
+            hbm_gbps = round(traffic / avg_launch_s / 1e9, 1) if traffic and avg_launch_s > 0 else None
+            mfma_busy = None
+            mfma_src = None
+            try:
+                util = traffic_src.replace("pmc_traffic.json", "pmc_util.txt") if traffic_src else None
+                if util:
+                    sect, vals = None, {}
+                    for ln in open(os.path.join(ROOT, "profiles", util)):
+                        if ln.startswith("=="):
+                            sect = ln.split()[1]
+                        elif sect in ("gemm16v5_kernel", "gemm8_kernel") and "avg=" in ln:
+                            vals.setdefault(sect, {})[ln.split()[0]] = float(ln.split("avg=")[1])
+                    v = vals.get("gemm8_kernel" if a.precision == "fp8" else "gemm16v5_kernel")
+                    if v and v.get("GRBM_GUI_ACTIVE"):
+                        mfma_busy = round(100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * 128.0), 1)
+                        mfma_src = util
+            except Exception:
+                mfma_busy = None
             roofline = {"bound": "mfma", "kernel": ("gemm8_kernel (fp8 block-scaled MFMA, the blocks' 4 projections) + the stem / neck fp16 GEMMs" if a.precision == "fp8"
                                                     else "gemm16v5_kernel<T,320|256,3> (all 16-bit MFMA GEMM launches)"),
                         "folded_layernorm": bool(hub.fold_ln) and a.precision == "fp16" or hub.fold_ln == "all" and a.precision == "bf16",
@@ -420,6 +442,10 @@ def main() -> None:
                         "achieved": round(achieved, 2), "peak": peak,
                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                         "traffic_note": f"HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/{traffic_src} (tools/pmc_summarize.py)" if traffic_src else None,
+                        "hbm_gbps": hbm_gbps, "hbm_peak_gbps": 8000.0, "hbm_frac": round(hbm_gbps / 8000.0, 4) if hbm_gbps else None,
+                        "mfma_busy_pct": mfma_busy,
+                        "mfma_busy_note": (f"matrix pipe busy cycles / (GPU-active cycles x SIMDs), rocprofv3 --pmc pass under the profiler's clock, "
+                                           f"profiles/{mfma_src} (tools/pmc_kernel.py)") if mfma_src else None,
                         "launches_per_step": g["launches"] // a.steps,
                         "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
                         "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
