@@ -16,6 +16,7 @@ ap.add_argument("--act", type=int, default=0)
 ap.add_argument("--f32out", action="store_true")
 ap.add_argument("--residual", action="store_true", help="fp32 residual added in the epilogue (implies --f32out)")
 ap.add_argument("--packed", action="store_true", help="A and W in LDS-image order (as the engine feeds the block GEMMs)")
+ap.add_argument("--out-packed", action="store_true", help="with --packed: the 16-bit output in LDS-image order too (lin1's form)")
 a = ap.parse_args()
 M = a.batch * 4096
 shapes = {"qkv": (M, 3840, 1280), "proj": (M, 1280, 1280), "lin1": (M, 5120, 1280), "lin2": (M, 1280, 5120),
@@ -38,7 +39,7 @@ for name in names:
     if a.packed:
         from wildlifemapper_amd import _native as Nn
         A, W = G.pack16(A), G.pack16(W)
-        layout = Nn.GEMM_W_PACKED | Nn.GEMM_A_PACKED
+        layout = Nn.GEMM_W_PACKED | Nn.GEMM_A_PACKED | (Nn.GEMM_OUT_PACKED if a.out_packed else 0)
     for _ in range(3):
         G.gemm16(A, W, bias, residual=res, act=a.act, prec=a.prec, want32=f32, want16=not f32, layout=layout)
     torch.cuda.synchronize()
