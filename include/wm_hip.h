@@ -29,11 +29,12 @@
 extern "C" {
 #endif
 
-/* 2 (round 3): wm_config.fp8_gemms; wm_debug_saturation_*; wm_op_layernorm rejects WM_PREC_FP8 with an fp32 output;
+/* 3 (round 3, second half): wm_op_encoder_attention_qkv added; nothing else changed.
+ * 2 (round 3): wm_config.fp8_gemms; wm_debug_saturation_*; wm_op_layernorm rejects WM_PREC_FP8 with an fp32 output;
  * wm_profile_read no longer reports the fused-LayerNorm time-out (wm_forward / wm_encoder_forward do); precision value 2
  * (fp8), WM_FLAG_MERGED and a NULL handle in wm_postprocess_nms date from round 2.  The Python binding refuses a library
  * whose wm_abi_version() differs from the value it was written for. */
-#define WM_ABI_VERSION 2
+#define WM_ABI_VERSION 3
 
 /* operand type of the transformer blocks' MFMA GEMMs / attention (accumulation, residual stream, LayerNorm
  * statistics, softmax and the whole decoder are fp32; the stem, the HFC adaptor and the neck -- 2.9 % of the

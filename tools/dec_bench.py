@@ -22,14 +22,14 @@ def ref_mha(q, k, v, heads):
     a = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(hd), -1)
     return (a @ vh).transpose(1, 2).reshape(B, nq, C).float()
 
-B = 4
+B = int(os.environ.get("DEC_B", "4"))
 for name, nq, nk, C in (("t2i", 51, 4096, 128), ("i2t", 4096, 51, 128), ("self", 51, 51, 256)):
     q = torch.randn(B, nq, C, device=dev); k = torch.randn(B, nk, C, device=dev); v = torch.randn(B, nk, C, device=dev)
     out = G.mha32(q, k, v, 8)
     err = (out - ref_mha(q, k, v, 8)).abs().max().item()
     print(f"mha32 {name:5s} nq={nq} nk={nk} C={C}: {timeit(lambda: G.mha32(q, k, v, 8)):8.1f} us  max err {err:.2e}", flush=True)
-for name, M, N, K in (("tok 256->256", 204, 256, 256), ("tok 256->128", 204, 128, 256), ("tok 128->256", 204, 256, 128), ("mlp1", 204, 2048, 256),
-                      ("mlp2", 204, 256, 2048), ("head8", 204, 8, 256), ("keys 256->128", 16384, 128, 256), ("keys 128->256", 16384, 256, 128)):
+for name, M, N, K in (("tok 256->256", 51 * B, 256, 256), ("tok 256->128", 51 * B, 128, 256), ("tok 128->256", 51 * B, 256, 128), ("mlp1", 51 * B, 2048, 256),
+                      ("mlp2", 51 * B, 256, 2048), ("head8", 51 * B, 8, 256), ("keys 256->128", 4096 * B, 128, 256), ("keys 128->256", 4096 * B, 256, 128)):
     a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) / math.sqrt(K); bias = torch.randn(N, device=dev)
     out = G.gemm32(a, w, bias)
     err = (out - (a.double() @ w.double().t() + bias.double()).float()).abs().max().item()

@@ -22,7 +22,7 @@ FLAG_CONF, FLAG_SCORE, FLAG_NMS, FLAG_MERGED = 1, 2, 4, 8
 CFG_FUSE_LN = 1
 CFG_FOLD_LN = 2
 CFG_FOLD_LN_BF16 = 4
-ABI_VERSION = 2            # include/wm_hip.h WM_ABI_VERSION this binding was written for
+ABI_VERSION = 3            # include/wm_hip.h WM_ABI_VERSION this binding was written for
 FP8_QKV, FP8_PROJ, FP8_MLP, FP8_ALL = 1, 2, 4, 7
 GEMM_W_PACKED, GEMM_A_PACKED, GEMM_OUT_PACKED, LAYOUT_PACKED = 0x1000, 0x2000, 0x4000, 0x100
 SAT_NAMES = ("layernorm_out", "qkv", "attention_out", "mlp_hidden", "last_block_16")
