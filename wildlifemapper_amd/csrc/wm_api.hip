@@ -9,6 +9,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <set>
 #include <string>
@@ -81,6 +82,25 @@ static int set_max_lds(const void* fn, int bytes) {
     if (done.count({fn, dev})) return 0;
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     done.insert({fn, dev});
+    return 0;
+}
+
+// Scratch memory of the handle-less single-op entry points (tests, tools), one buffer per (device, stream, use): a stream's launches
+// are ordered, two streams never share a buffer.  Grown by free + malloc (hipFree synchronises the device).  Handles own their own.
+static int op_scratch(hipStream_t s, int use, size_t bytes, void** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    static std::map<std::tuple<int, hipStream_t, int>, Buf> bufs;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    Buf& b = bufs[std::make_tuple(dev, s, use)];
+    if (b.cap < bytes) {
+        if (b.p) hipFree(b.p);
+        b.p = nullptr; b.cap = 0;
+        HIP_TRY(hipMalloc(&b.p, bytes));
+        b.cap = bytes;
+    }
+    *out = b.p;
     return 0;
 }
 
@@ -773,8 +793,6 @@ int launch_encoder_attention(wm_handle* h, hipStream_t s, int prec, const void* 
     }
     if (window != 14) return fail("attention: window=%d unsupported (14 or 0)", window);
     {   // the bias as a 16-bit row (AttnArgs::qkv_bias16): cached per handle, converted per call without one
-        static uint16_t* op_buf = nullptr;
-        static int op_cap = 0;
         uint16_t* b16 = nullptr;
         bool convert = true;
         if (h) {
@@ -782,8 +800,9 @@ int launch_encoder_attention(wm_handle* h, hipStream_t s, int prec, const void* 
             if (it != h->bias16.end()) { b16 = it->second; convert = false; }
             else { WM_TRY(dalloc(h, &b16, (size_t)3 * D * 2)); h->bias16[{qkv_bias, prec}] = b16; }
         } else {
-            if (op_cap < 3 * D) { if (op_buf) hipFree(op_buf); HIP_TRY(hipMalloc((void**)&op_buf, (size_t)3 * D * 2)); op_cap = 3 * D; }
-            b16 = op_buf;
+            void* pb = nullptr;
+            WM_TRY(op_scratch(s, 0, (size_t)3 * D * 2, &pb));
+            b16 = (uint16_t*)pb;
         }
         if (convert) {
             if (prec == WM_PREC_FP16) hipLaunchKernelGGL(cvt_f32_to_16_kernel<FP16>, dim3((3 * D / 4 + 255) / 256), dim3(256), 0, s, qkv_bias, (u16*)b16, (int64_t)(3 * D / 4));
@@ -819,19 +838,22 @@ int launch_mha32(wm_handle* h, hipStream_t s, const float* q, const float* k, co
         // (or, for handle-less op calls, of the process)
         const int nchunk = nk / KC;
         const size_t need = (size_t)batch * heads * nchunk * 64 * (16 + 2) * 4;
-        static float* op_part = nullptr;
-        static size_t op_cap = 0;
-        float** buf = h ? &h->mha_part : &op_part;
-        size_t* cap = h ? &h->mha_part_cap : &op_cap;
-        if (*cap < need) {
-            if (*buf) { HIP_TRY(hipStreamSynchronize(s)); hipFree(*buf); if (h) for (auto& a : h->allocs) if (a == *buf) a = nullptr; }
-            void* pnew = nullptr;
-            HIP_TRY(hipMalloc(&pnew, need));
-            if (h) h->allocs.push_back(pnew);
-            *buf = (float*)pnew; *cap = need;
+        float* part = nullptr;
+        if (h) {
+            if (h->mha_part_cap < need) {
+                if (h->mha_part) { hipFree(h->mha_part); for (auto& a : h->allocs) if (a == h->mha_part) a = nullptr; }     // hipFree synchronises
+                h->mha_part = nullptr; h->mha_part_cap = 0;
+                WM_TRY(dalloc(h, &h->mha_part, need));
+                h->mha_part_cap = need;
+            }
+            part = h->mha_part;
+        } else {
+            void* pb = nullptr;
+            WM_TRY(op_scratch(s, 1, need, &pb));
+            part = (float*)pb;
         }
-        hipLaunchKernelGGL((mha32_keysplit_kernel<16, KC>), dim3(nchunk, heads, batch), dim3(256), 0, s, q, k, v, *buf, nq, nk, heads);
-        hipLaunchKernelGGL((mha32_merge_chunks_kernel<16>), dim3(heads, batch), dim3(64 * 4), 0, s, (const float*)*buf, out, nq, nchunk, heads);
+        hipLaunchKernelGGL((mha32_keysplit_kernel<16, KC>), dim3(nchunk, heads, batch), dim3(256), 0, s, q, k, v, part, nq, nk, heads);
+        hipLaunchKernelGGL((mha32_merge_chunks_kernel<16>), dim3(heads, batch), dim3(64 * 4), 0, s, (const float*)part, out, nq, nchunk, heads);
     } else if (hd == 16 && nk == NQ && nq >= 1024)       // image -> token: one thread per query, K / V from scalar loads
         hipLaunchKernelGGL((mha32_fewkeys_kernel<16, NQ>), dim3((nq + 255) / 256, heads, batch), dim3(256), 0, s, q, k, v, out, nq, heads);
     else if (hd == 16 && share) hipLaunchKernelGGL((mha32_kernel<16, 4, 4>), dim3((nq + 3) / 4, heads, batch), dim3(256), 0, s, q, k, v, out, nq, nk, heads);
