@@ -40,10 +40,13 @@ __device__ __forceinline__ unsigned lds_base_opaque(const char* p) {
 // waits are this file's (bar_landed).
 // `lanes` = the lanes that take part (a piece's pad chunks do not; 0 = this wave has no such piece): EXEC is narrowed inside the asm,
 // because a C++ `if` costs two taken branches per piece (~100 cycles per piece in the timeline).
+// M0 (the DMA's LDS base) is reserved to the compiler -- a clobber of it is not honoured -- so the asm saves and restores it.
 __device__ __forceinline__ void dma16_to_lds(const void* gptr, unsigned lds_addr, unsigned long long lanes) {
     unsigned long long saved;
-    asm volatile("s_mov_b32 m0, %2\n\ts_and_saveexec_b64 %0, %3\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b64 exec, %0"
-                 : "=&s"(saved) : "v"(gptr), "s"(lds_addr), "s"(lanes) : "memory", "m0", "scc");
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_and_saveexec_b64 %0, %4\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1"
+                 : "=&s"(saved), "=&s"(m0_saved) : "v"(gptr), "s"(lds_addr), "s"(lanes) : "memory", "scc");
 }
 template <class T>
 __device__ __forceinline__ typename T::vec8 lds_read_v8_at(unsigned base, int off) {

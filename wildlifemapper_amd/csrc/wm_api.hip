@@ -1361,7 +1361,7 @@ int sat_check(wm_handle* h, hipStream_t s, int which, const void* buf, int64_t n
 }
 
 int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw, int B, hipStream_t s) {
-    const int D = h->D, P = h->prec, M = B * T;
+    const int D = h->D, M = B * T;
     const int PS = WM_PREC_FP16;      // stem, HFC adaptor and neck: fp16 operands in every mode (see is_stem_or_neck)
     const std::string e = "image_encoder.", a = e + "hfc_attn.";
     // ---- stem: patch / HFC embeds (image_encoder.py:124-128) ----
