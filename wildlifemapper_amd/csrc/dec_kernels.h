@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void mha32_keysplit_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z, nchunk = gridDim.x;
     const int C = heads * HD;
-    const float scale = 1.0f / sqrtf((float)HD);
+    const float scale = 1.44269504088896340736f / sqrtf((float)HD);      // scores in the log2 domain: exp2 is one instruction
     const float* kb = k + ((size_t)b * nk + (size_t)chunk * KC) * C + head * HD;
     const float* vb = v + ((size_t)b * nk + (size_t)chunk * KC) * C + head * HD;
     constexpr int CPR = HD / 4;                               // 16-byte chunks per row
@@ -130,34 +130,48 @@ __global__ __launch_bounds__(256) void mha32_keysplit_kernel(const float* __rest
 #pragma unroll
         for (int d = 0; d < HD; d += 4) {
             const f32x4 t = *(const f32x4*)(qp + d);
-            qv[d] = t[0] * scale; qv[d + 1] = t[1] * scale; qv[d + 2] = t[2] * scale; qv[d + 3] = t[3] * scale;
+            qv[d] = t[0] * scale; qv[d + 1] = t[1] * scale; qv[d + 2] = t[2] * scale; qv[d + 3] = t[3] * scale;    // scale includes log2 e
         }
     }
     float m = -1e30f, l = 0.f;
 #pragma unroll
     for (int d = 0; d < HD; ++d) acc[d] = 0.f;
     __syncthreads();
-    constexpr int KW = KC / 4;
-#pragma unroll 2
-    for (int j = 0; j < KW; ++j) {
-        const float* kr = sK + (wave * KW + j) * HD;          // wave-uniform address: an LDS broadcast
-        const float* vr = sV + (wave * KW + j) * HD;
-        float sc = 0.f;
+    constexpr int KW = KC / 4, KB = 8;                       // keys per wave; keys per softmax block (one rescale of acc per block)
+    static_assert(KW % KB == 0, "key blocks");
+    for (int j0 = 0; j0 < KW; j0 += KB) {
+        float sc[KB];
+        float bm = -1e30f;
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) {
-            const f32x4 t = *(const f32x4*)(kr + d);
-            sc = fmaf(qv[d], t[0], sc); sc = fmaf(qv[d + 1], t[1], sc); sc = fmaf(qv[d + 2], t[2], sc); sc = fmaf(qv[d + 3], t[3], sc);
-        }
-        const float mn = fmaxf(m, sc);
-        const float a = expf(m - mn), pe = expf(sc - mn);
-        l = l * a + pe;
+        for (int j = 0; j < KB; ++j) {
+            const float* kr = sK + (wave * KW + j0 + j) * HD;    // wave-uniform address: an LDS broadcast
+            float t0 = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) {
-            const f32x4 u = *(const f32x4*)(vr + d);
-            acc[d] = fmaf(acc[d], a, pe * u[0]); acc[d + 1] = fmaf(acc[d + 1], a, pe * u[1]);
-            acc[d + 2] = fmaf(acc[d + 2], a, pe * u[2]); acc[d + 3] = fmaf(acc[d + 3], a, pe * u[3]);
+            for (int d = 0; d < HD; d += 4) {
+                const f32x4 t = *(const f32x4*)(kr + d);
+                t0 = fmaf(qv[d], t[0], t0); t0 = fmaf(qv[d + 1], t[1], t0); t0 = fmaf(qv[d + 2], t[2], t0); t0 = fmaf(qv[d + 3], t[3], t0);
+            }
+            sc[j] = t0;
+            bm = fmaxf(bm, t0);
         }
+        const float mn = fmaxf(m, bm);
+        const float a = __builtin_amdgcn_exp2f(m - mn);
+        l *= a;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] *= a;
         m = mn;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const float* vr = sV + (wave * KW + j0 + j) * HD;
+            const float pe = __builtin_amdgcn_exp2f(sc[j] - mn);
+            l += pe;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const f32x4 u = *(const f32x4*)(vr + d);
+                acc[d] = fmaf(pe, u[0], acc[d]); acc[d + 1] = fmaf(pe, u[1], acc[d + 1]);
+                acc[d + 2] = fmaf(pe, u[2], acc[d + 2]); acc[d + 3] = fmaf(pe, u[3], acc[d + 3]);
+            }
+        }
     }
 #pragma unroll
     for (int d = 0; d < HD; ++d) sP[wave][lane][d] = acc[d];
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(256) void mha32_keysplit_kernel(const float* __rest
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const float f = expf(sP[w][qi][HD] - M);
+                const float f = __builtin_amdgcn_exp2f(sP[w][qi][HD] - M);
                 L += sP[w][qi][HD + 1] * f;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) o[jj] += sP[w][qi][d0 + jj] * f;
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(256) void mha32_keysplit_kernel(const float* __rest
     }
 }
 
-// out[b][q][head*HD + d] = sum_chunks o f / sum_chunks l f, f = exp(m_chunk - max m).  grid (heads, B), 64 * HD / 4 threads
+// out[b][q][head*HD + d] = sum_chunks o f / sum_chunks l f, f = exp2(m_chunk - max m).  grid (heads, B), 64 * HD / 4 threads
 template <int HD>
 __global__ void mha32_merge_chunks_kernel(const float* __restrict__ part, float* __restrict__ out, int nq, int nchunk, int heads) {
     const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -200,7 +214,7 @@ __global__ void mha32_merge_chunks_kernel(const float* __restrict__ part, float*
     float L = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < nchunk; ++c) {
-        const float f = expf(src[c * cs + HD] - M);
+        const float f = __builtin_amdgcn_exp2f(src[c * cs + HD] - M);      // the partial maxima are log2-domain
         L += src[c * cs + HD + 1] * f;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) o[jj] += src[c * cs + d0 + jj] * f;

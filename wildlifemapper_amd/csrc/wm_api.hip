@@ -1544,9 +1544,8 @@ __global__ __launch_bounds__(256) void add_bcast_kernel(const float* __restrict_
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const int64_t r = (i * 4) / C;
         const int c = (int)((i * 4) % C);
-        const f32x4 x = *(const f32x4*)(a + i * 4);
         const f32x4 y = *(const f32x4*)(b + (r % mod) * C + c);
-        *(f32x4*)(out + i * 4) = x + y;
+        *(f32x4*)(out + i * 4) = a ? *(const f32x4*)(a + i * 4) + y : y;        // a == null: the rows of b repeated
     }
 }
 
@@ -1559,8 +1558,8 @@ int decoder_impl(wm_handle* h, const float* keys_nhwc, float* logits, float* box
     float* keys = h->dkeys;
     HIP_TRY(hipMemcpyAsync(keys, keys_nhwc, (size_t)Mk * E * 4, hipMemcpyDeviceToDevice, s));
     float* queries = h->dq;
-    for (int b = 0; b < B; ++b)
-        HIP_TRY(hipMemcpyAsync(queries + (size_t)b * NQ * E, tok, (size_t)NQ * E * 4, hipMemcpyDeviceToDevice, s));
+    // every tile starts from the same 51 tokens (one launch; it was one copy per tile)
+    WM_TRY(launch_simple(h, s, 0.0, add_bcast_kernel, dim3(grid_for((int64_t)Mq * E / 4)), dim3(256), (const float*)nullptr, tok, queries, (int64_t)Mq, E, NQ));
 
     auto add_q = [&](float* out) {   // queries + query_pe
         return launch_simple(h, s, 0.0, add_bcast_kernel, dim3(grid_for((int64_t)Mq * E / 4)), dim3(256), (const float*)queries, tok, out, (int64_t)Mq, E, NQ);
