@@ -25,7 +25,12 @@ __global__ __launch_bounds__(256) void gemm32_kernel(Gemm32Args p) {
     __shared__ float sW[BN * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // 1-D grid, XCD-aware: the column tiles of one row block read the same A rows, so they get consecutive logical ids = one XCD's
+    // L2 (as a 2-D grid they were dealt round-robin over the XCDs and A came from HBM once per column tile: the decoder's
+    // M = 65536-row projections, N = 128 / 256)
+    const int ntn = (p.N + BN - 1) / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
     const int lrow = tid >> 2, lcol = (tid & 3) * 8;          // 8 consecutive k per thread and operand
 
     f32x16 acc;

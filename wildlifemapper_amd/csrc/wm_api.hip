@@ -624,7 +624,7 @@ int launch_gemm32(wm_handle* h, hipStream_t s, const float* A, const float* W, c
     if (K % 16) return fail("gemm32: K=%d must be a multiple of 16", K);
     Gemm32Args a{A, W, bias, res, out, M, N, K, act, lda > 0 ? lda : K};
     Bracket br(h, s, WM_KCLASS_OTHER, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    hipLaunchKernelGGL(gemm32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gemm32_kernel, dim3(((N + 63) / 64) * ((M + 63) / 64)), dim3(256), 0, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
