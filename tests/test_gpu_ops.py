@@ -603,6 +603,24 @@ def test_mha16_hfc_shape(prec):
     assert G.rel_l2(out.float(), ref) < 2 * OUT16_TOL[prec]
 
 
+@pytest.mark.parametrize("nq,nk,hd", [(256, 128, 80), (512, 192, 80), (256, 256, 64), (128, 192, 80), (384, 64, 80)])
+def test_mha16_short_key_counts(nq, nk, hd):
+    """Key counts of 2, 3 and 4 tiles of 64: the 8-wave kernel's 3-slot K / V ring below, at and just past its depth (nq a
+    multiple of 256, nk >= 128); (128, 192) and (384, 64) fall outside its geometry and take the 4-wave kernel."""
+    B, heads, prec, dev = 2, 2, "fp16", G.dev()
+    torch.manual_seed(nq + nk)
+    q = G.to16(torch.randn(B * nq, heads * hd, device=dev), prec)
+    k = G.to16(torch.randn(B * nk, heads * hd, device=dev), prec)
+    v = G.to16(torch.randn(B * nk, heads * hd, device=dev), prec)
+    out = G.mha16(q, k, v, B, heads, hd, nq, nk, prec)
+    qf = q.float().view(B, nq, heads, hd).permute(0, 2, 1, 3)
+    kf = k.float().view(B, nk, heads, hd).permute(0, 2, 1, 3)
+    vf = v.float().view(B, nk, heads, hd).permute(0, 2, 1, 3)
+    p = _rnd(((qf @ kf.transpose(-1, -2)) / math.sqrt(hd)).softmax(-1), prec)
+    ref = (p @ vf).permute(0, 2, 1, 3).reshape(B * nq, heads * hd)
+    assert G.rel_l2(out.float(), ref) < 2 * OUT16_TOL[prec]
+
+
 def C_off(t, elems):
     import ctypes
     return ctypes.c_void_p(t.data_ptr() + elems * t.element_size())
