@@ -398,9 +398,12 @@ def main() -> None:
             traffic_src = None
             try:   # HBM bytes per GEMM launch from the PMC passes committed under profiles/ (collected offline with rocprofv3)
                 folded = bool(hub.fold_ln) and a.precision == "fp16"       # the default path: its own counter files
-                for name in ((f"r3_final_{a.precision}_pmc_traffic.json" if folded else f"r3_{a.precision}_pmc_traffic.json"),
+                final_tree = folded or (a.precision in ("bf16", "fp8") and not hub.fold_ln == "all")     # collected with these defaults
+                for name in ((f"r3_final_{a.precision}_pmc_traffic.json" if final_tree else f"r3_{a.precision}_pmc_traffic.json"),
                              ("r2_pmc_traffic.json" if a.precision == "bf16" else f"r2_{a.precision}_pmc_traffic.json"),
                              "r1g_pmc_traffic.json"):   # newest round first; bf16 keeps its round-2 file name
+                    if not os.path.exists(os.path.join(ROOT, "profiles", name)):
+                        continue
                     with open(os.path.join(ROOT, "profiles", name)) as f:
                         t = json.load(f)
                     # the committed counters belong to one workload: use them only for that one
