@@ -108,85 +108,126 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
     f32x16 relw[2];
     float* sRelH = (float*)smem + wave * L::WAVE_F;
 
+#if WM_DEV_TIMELINE
+    // dev: coarse stamps in slots 60..63 of the wave's timeline: kernel entry, rel-pos prologue done, K / V prologue done, key loop done
+    auto stamp_at = [&](int slot) {
+        if (p.tl && blockIdx.x == 0) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            if (lane == 0) ((unsigned long long*)(smem + L::TOTAL) + wave * 64)[slot] = t;
+        }
+    };
+    stamp_at(60);
+#define WM_G8_COARSE(slot) stamp_at(slot)
+#else
+#define WM_G8_COARSE(slot)
+#endif
     if constexpr (REL) {
         // ---- prologue: rel_w (registers) and rel_h (LDS) for this wave's 32 queries; as attn_global_kernel ----
         const int qh = q0 >> 6, qw0 = q0 & 63;
         const float inv_scale = 1.0f / p.scale;
         char* sTab = sKV;
         float* sT = (float*)smem + wave * L::WAVE_F;          // [query c][65] fp32 staging
-#pragma unroll 1
-        for (int which = 0; which < 2; ++which) {
-            const float* tab = which == 0 ? p.rel_w : p.rel_h;
-            __syncthreads();
-            for (int e = tid; e < 128 * (HD / 4); e += 512) {
-                const int row = e / (HD / 4), c4 = e % (HD / 4);
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (row < 127) v = *(const f32x4*)(tab + (size_t)row * HD + c4 * 4);
+        // both tables staged at once (the K / V ring is idle and holds them side by side), one barrier pair
+        static_assert(3 * L::TILE >= 256 * G::KS, "both rel-pos table images are staged in the K / V ring");
+        __syncthreads();
+        {   // all of a thread's table chunks are requested before the first is converted (as a rolled loop each load was waited for
+            // in turn: ~12k cycles of the prologue in the timeline)
+            constexpr int NTC = 256 * (HD / 4) / 512;
+            static_assert(256 * (HD / 4) % 512 == 0, "table chunks per thread");
+            f32x4 tv[NTC];
+#pragma unroll
+            for (int i = 0; i < NTC; ++i) {
+                const int e = tid + i * 512, row = e / (HD / 4), c4 = e % (HD / 4);
+                const float* tab = row < 128 ? p.rel_w : p.rel_h;
+                const int tr = min(row & 127, 126);              // row 127 of an image is zero (below)
+                tv[i] = *(const f32x4*)(tab + (size_t)tr * HD + c4 * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NTC; ++i) {
+                const int e = tid + i * 512, row = e / (HD / 4), c4 = e % (HD / 4);
                 typename T::vec4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[j]);
+                for (int j = 0; j < 4; ++j) o[j] = (row & 127) < 127 ? T::from_f32(tv[i][j]) : T::from_f32(0.f);
                 *(typename T::vec4*)(sTab + row * G::KS + c4 * 8) = o;
             }
-            __syncthreads();
-            if (which == 0) {
-                const int qw = qw0 + c;
+        }
+        __syncthreads();
+        WM_G8_COARSE(48);
+        {   // rel_w: T[c][i] = q_c . table_w[i] for the 127 rows in two passes of 64; lane (c, h) keeps the entries its keys need
+            const int qw = qw0 + c;
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) relw[t][r] = 0.f;
+                for (int r = 0; r < 16; ++r) relw[t][r] = 0.f;
 #pragma unroll 1
-                for (int pass = 0; pass < 2; ++pass) {
-                    f32x16 acc[2];
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-                    qk_tile<T, HD, 2>(acc, qf, sTab + pass * 64 * G::KS, lane);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int il = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            sT[c * 65 + il] = acc[t][r];
-                        }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int kw = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            const int idx = qw + 63 - kw;
-                            if ((idx >> 6) == pass) relw[t][r] = sT[c * 65 + (idx & 63)] * inv_scale;
-                        }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                }
-            } else {
+            for (int pass = 0; pass < 2; ++pass) {
                 f32x16 acc[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-                const int r31 = lane & 31;
+                qk_tile<T, HD, 2>(acc, qf, sTab + pass * 64 * G::KS, lane);
 #pragma unroll
-                for (int ks = 0; ks < G::NKS; ++ks)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int row = qh + 63 - (32 * t + r31);
-                        typename T::vec8 kf = lds_read_v8<T>(sTab + row * G::KS + (16 * ks + 8 * h) * 2);
-                        acc[t] = T::mfma32(kf, qf[ks], acc[t]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int il = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        sT[c * 65 + il] = acc[t][r];
+                    }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                // every lane reads a (valid) entry and keeps it by select: as `if`s these were 32 divergent branches per pass
+                // (8.2k of the prologue's 26k cycles in the timeline)
+                float tv[2][16];                               // all 32 reads in flight, then the selects
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kw = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        tv[t][r] = sT[c * 65 + ((qw + 63 - kw) & 63)];
                     }
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int kh = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        sRelH[kh * 32 + c] = acc[t][r] * inv_scale;
+                        const int kw = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int idx = qw + 63 - kw;
+                        asm volatile("" : "+v"(tv[t][r]));     // the read stays unconditional (hipcc sinks it under the condition otherwise)
+                        relw[t][r] = (idx >> 6) == pass ? tv[t][r] * inv_scale : relw[t][r];
                     }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
             }
         }
+        WM_G8_COARSE(49);
+        {   // rel_h: the 64 table rows qh + 63 - kh of this wave's query row, straight from the table image
+            const char* sTabH = sTab + 128 * G::KS;
+            f32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            const int r31 = lane & 31;
+#pragma unroll
+            for (int ks = 0; ks < G::NKS; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int row = qh + 63 - (32 * t + r31);
+                    typename T::vec8 kf = lds_read_v8<T>(sTabH + row * G::KS + (16 * ks + 8 * h) * 2);
+                    acc[t] = T::mfma32(kf, qf[ks], acc[t]);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kh = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    sRelH[kh * 32 + c] = acc[t][r] * inv_scale;
+                }
+        }
+        WM_G8_COARSE(50);
         __syncthreads();
     }
 
+    WM_G8_COARSE(61);
     // ---- staging by LDS-DMA: the K image (64 rows x KS) is KS / 16 pieces of 1 KiB, the V image VS / 16; piece q belongs to wave
     // q % 8.  A lane's 16 B of a piece are (row, chunk) = ((1024 q + 16 lane) / stride, ... % stride / 16); lanes on a pad chunk
     // stay masked, so the V image's ones column (v_pad_ones) survives.  Address = wave-uniform base (K or V, + tile) + a per-lane
@@ -231,6 +272,7 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    WM_G8_COARSE(62);
     SoftmaxState<G::NDT> st;
     st.init();
     f32x16 s[NT];
@@ -242,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
     unsigned long long* tls = (unsigned long long*)(smem + L::TOTAL) + wave * 64;
     const bool tl_on = p.tl && blockIdx.x == 0;
     auto stamp = [&](int k, int j) {
-        if (tl_on && j >= 4 && j < 9) {
+        if (tl_on && j >= 4 && j < 8) {                    // slots 48..59 belong to the coarse prologue stamps
             unsigned long long t;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
             if (lane == 0) tls[(j - 4) * 12 + k] = t;
@@ -415,6 +457,7 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
         v_phase(ntiles - 1); bar();
         m_phase(ntiles, yes, no); bar();
     }
+    WM_G8_COARSE(63);
 #if WM_DEV_TIMELINE
     __syncthreads();
     if (tl_on && lane == 0)
