@@ -108,6 +108,44 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
     f32x16 relw[2];
     float* sRelH = (float*)smem + wave * L::WAVE_F;
 
+    // ---- staging by LDS-DMA (tile j lives in ring slot (j + 2) % 3: slot 2 is free while the rel-pos tables occupy slots 0 and 1, so tile 0
+    // is requested before the rel-pos arithmetic and lands under it): the K image (64 rows x KS) is KS / 16 pieces of 1 KiB, the V image VS / 16; piece q belongs to wave
+    // q % 8.  A lane's 16 B of a piece are (row, chunk) = ((1024 q + 16 lane) / stride, ... % stride / 16); lanes on a pad chunk
+    // stay masked, so the V image's ones column (v_pad_ones) survives.  Address = wave-uniform base (K or V, + tile) + a per-lane
+    // 32-bit offset computed once: no vector instruction per tile, no staging registers, no ds_write.
+    const int ntiles = p.nk / 64;
+    constexpr int NPK = G::KS / 16, NPV = G::VS / 16, NPIECE = NPK + NPV;
+    constexpr int PER = (NPIECE + 7) / 8;
+    static_assert(PER <= 5, "pieces per wave");
+    struct Piece { bool isv; unsigned long long lanes; unsigned voff; int lds_off; };
+    auto piece_setup = [&](int i) {
+        Piece d;
+        const int q = wave + 8 * i;
+        d.isv = q >= NPK;
+        const int ql = d.isv ? q - NPK : q;
+        const int stride = d.isv ? G::VS : G::KS;
+        const int B = ql * 1024 + lane * 16;
+        const int row = B / stride, ch = (B % stride) / 16;
+        const bool live = q < NPIECE && ch < G::CH;
+        d.lanes = __ballot(live);
+        d.voff = live ? (unsigned)row * (unsigned)(d.isv ? p.v_stride : p.k_stride) * 2u + ch * 16u : 0u;
+        d.lds_off = (d.isv ? L::K_BYTES : 0) + ql * 1024;
+        return d;
+    };
+    const Piece pc0 = piece_setup(0), pc1 = piece_setup(1), pc2 = piece_setup(2), pc3 = piece_setup(3), pc4 = piece_setup(4);
+    auto issue1 = [&](const Piece& d, int tile) {
+        const char* base = d.isv ? (const char*)vb + (size_t)tile * 128u * (unsigned)p.v_stride
+                                 : (const char*)kb + (size_t)tile * 128u * (unsigned)p.k_stride;
+        const unsigned dst = (unsigned)(size_t)(lds_cptr_t)(sKV + ((tile + 2) % 3) * L::TILE + d.lds_off);
+        dma16_to_lds(base + d.voff, dst, d.lanes);
+    };
+    auto issue = [&](int tile) {
+        issue1(pc0, tile);
+        if constexpr (PER > 1) issue1(pc1, tile);
+        if constexpr (PER > 2) issue1(pc2, tile);
+        if constexpr (PER > 3) issue1(pc3, tile);
+        if constexpr (PER > 4) issue1(pc4, tile);
+    };
 #if WM_DEV_TIMELINE
     // dev: coarse stamps in slots 60..63 of the wave's timeline: kernel entry, rel-pos prologue done, K / V prologue done, key loop done
     auto stamp_at = [&](int slot) {
@@ -153,6 +191,7 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
             }
         }
         __syncthreads();
+        issue(0);
         WM_G8_COARSE(48);
         {   // rel_w: T[c][i] = q_c . table_w[i] for the 127 rows in two passes of 64; lane (c, h) keeps the entries its keys need
             const int qw = qw0 + c;
@@ -228,46 +267,9 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
     }
 
     WM_G8_COARSE(61);
-    // ---- staging by LDS-DMA: the K image (64 rows x KS) is KS / 16 pieces of 1 KiB, the V image VS / 16; piece q belongs to wave
-    // q % 8.  A lane's 16 B of a piece are (row, chunk) = ((1024 q + 16 lane) / stride, ... % stride / 16); lanes on a pad chunk
-    // stay masked, so the V image's ones column (v_pad_ones) survives.  Address = wave-uniform base (K or V, + tile) + a per-lane
-    // 32-bit offset computed once: no vector instruction per tile, no staging registers, no ds_write.
-    const int ntiles = p.nk / 64;
-    constexpr int NPK = G::KS / 16, NPV = G::VS / 16, NPIECE = NPK + NPV;
-    constexpr int PER = (NPIECE + 7) / 8;
-    static_assert(PER <= 5, "pieces per wave");
-    struct Piece { bool isv; unsigned long long lanes; unsigned voff; int lds_off; };
-    auto piece_setup = [&](int i) {
-        Piece d;
-        const int q = wave + 8 * i;
-        d.isv = q >= NPK;
-        const int ql = d.isv ? q - NPK : q;
-        const int stride = d.isv ? G::VS : G::KS;
-        const int B = ql * 1024 + lane * 16;
-        const int row = B / stride, ch = (B % stride) / 16;
-        const bool live = q < NPIECE && ch < G::CH;
-        d.lanes = __ballot(live);
-        d.voff = live ? (unsigned)row * (unsigned)(d.isv ? p.v_stride : p.k_stride) * 2u + ch * 16u : 0u;
-        d.lds_off = (d.isv ? L::K_BYTES : 0) + ql * 1024;
-        return d;
-    };
-    const Piece pc0 = piece_setup(0), pc1 = piece_setup(1), pc2 = piece_setup(2), pc3 = piece_setup(3), pc4 = piece_setup(4);
-    auto issue1 = [&](const Piece& d, int tile) {
-        const char* base = d.isv ? (const char*)vb + (size_t)tile * 128u * (unsigned)p.v_stride
-                                 : (const char*)kb + (size_t)tile * 128u * (unsigned)p.k_stride;
-        const unsigned dst = (unsigned)(size_t)(lds_cptr_t)(sKV + (tile % 3) * L::TILE + d.lds_off);
-        dma16_to_lds(base + d.voff, dst, d.lanes);
-    };
-    auto issue = [&](int tile) {
-        issue1(pc0, tile);
-        if constexpr (PER > 1) issue1(pc1, tile);
-        if constexpr (PER > 2) issue1(pc2, tile);
-        if constexpr (PER > 3) issue1(pc3, tile);
-        if constexpr (PER > 4) issue1(pc4, tile);
-    };
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) v_pad_ones<T, HD>(sKV + sl * L::TILE + L::K_BYTES, 64, tid, 512);
-    issue(0);
+    if constexpr (!REL) issue(0);
     if (ntiles > 1) issue(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -305,8 +307,8 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
         // staging turn of waves 0-3: their pieces of tile j + 1; see the header
         if (grp == 0 && j >= 1 && j + 1 < ntiles) issue(j + 1);
         WM_G8_STAMP(3, j - 1);
-        const char* sV = sKV + ((j + 2) % 3) * L::TILE + L::K_BYTES;          // slot of tile j - 1
-        const char* sK = sKV + (j % 3) * L::TILE;
+        const char* sV = sKV + ((j + 1) % 3) * L::TILE + L::K_BYTES;          // slot of tile j - 1
+        const char* sK = sKV + ((j + 2) % 3) * L::TILE;
         const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
         const int v_lane_off = (4 * (g >> 1) + lq) * G::VS + (16 * (g & 1) + 4 * lp) * 2;
         const int r31 = lane & 31;

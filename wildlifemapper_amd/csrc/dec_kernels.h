@@ -118,10 +118,22 @@ __global__ __launch_bounds__(256) void mha32_keysplit_kernel(const float* __rest
     const float* kb = k + ((size_t)b * nk + (size_t)chunk * KC) * C + head * HD;
     const float* vb = v + ((size_t)b * nk + (size_t)chunk * KC) * C + head * HD;
     constexpr int CPR = HD / 4;                               // 16-byte chunks per row
-    for (int e = tid; e < KC * CPR; e += 256) {
-        const int row = e / CPR, c4 = e % CPR;
-        *(f32x4*)(sK + row * HD + c4 * 4) = *(const f32x4*)(kb + (size_t)row * C + c4 * 4);
-        *(f32x4*)(sV + row * HD + c4 * 4) = *(const f32x4*)(vb + (size_t)row * C + c4 * 4);
+    {   // all of a thread's K / V chunks requested before the first is stored (a rolled loop waits for each load in turn)
+        constexpr int NCH = KC * CPR / 256;
+        static_assert(KC * CPR % 256 == 0, "chunks per thread");
+        f32x4 kx[NCH], vx[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int e = tid + i * 256, row = e / CPR, c4 = e % CPR;
+            kx[i] = *(const f32x4*)(kb + (size_t)row * C + c4 * 4);
+            vx[i] = *(const f32x4*)(vb + (size_t)row * C + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int e = tid + i * 256, row = e / CPR, c4 = e % CPR;
+            *(f32x4*)(sK + row * HD + c4 * 4) = kx[i];
+            *(f32x4*)(sV + row * HD + c4 * 4) = vx[i];
+        }
     }
     float qv[HD], acc[HD];
     {
