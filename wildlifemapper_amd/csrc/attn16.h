@@ -520,17 +520,19 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
         for (int i = 0; i < NPF; ++i) {
             const int e = tid_o + i * NTHR;
             const int key = e / G::CH, ch = e % G::CH;                                  // key slot = 16 kh + kw (kw 14, 15: zero rows)
-            s16x8 kv8 = s16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv8 = kv8;
-            if ((key & 15) < WS) {
-                // a token outside the image is zero after norm1, so its qkv row is the bias (image_encoder.py:190-194, 281): the row
-                // pointer is SELECTED, not branched on -- converting the fp32 bias here put 4 loads and a vmcnt(0) in the middle of
-                // every edge window's prefetch (timeline: 3-9k of an item's 23k cycles went into issuing it)
-                const int y = wy * WS + (key >> 4), x = wx * WS + (key & 15);
-                const bool in = y < GRID && x < GRID;
-                const size_t tok = (size_t)(y * GRID + x);
-                kv8 = *(const s16x8*)((in ? kbase + tok * p.k_stride : p.qkv_bias16 + D + head * HD) + ch * 8);
-                vv8 = *(const s16x8*)((in ? vbase + tok * p.v_stride : p.qkv_bias16 + 2 * D + head * HD) + ch * 8);
-            }
+            // A token outside the image is zero after norm1, so its qkv row is the bias (image_encoder.py:190-194, 281); the two pad
+            // columns of the 14 x 16 slot layout take the bias row too: their scores carry the -1e30 column bias, so P = 0 exactly
+            // whatever finite K / V they hold.  The row pointer is SELECTED bitwise -- as `if`s this was two exec-mask branches per
+            // chunk, and converting the fp32 bias here put 4 loads and a vmcnt(0) in the middle of every edge window's prefetch
+            // (timeline: 3-9k of an item's 23k cycles went into issuing it).
+            const int y = wy * WS + (key >> 4), x = wx * WS + (key & 15);
+            const bool in = (key & 15) < WS && y < GRID && x < GRID;
+            const size_t tok = (size_t)(min(y, GRID - 1) * GRID + min(x, GRID - 1));
+            const size_t msk = (size_t)0 - (size_t)in;
+            const u16* krow = (const u16*)(((size_t)(kbase + tok * p.k_stride) & msk) | ((size_t)(p.qkv_bias16 + D + head * HD) & ~msk));
+            const u16* vrow = (const u16*)(((size_t)(vbase + tok * p.v_stride) & msk) | ((size_t)(p.qkv_bias16 + 2 * D + head * HD) & ~msk));
+            const s16x8 kv8 = *(const s16x8*)(krow + ch * 8);
+            const s16x8 vv8 = *(const s16x8*)(vrow + ch * 8);
             kreg[i] = kv8;
             vreg[i] = vv8;
         }
