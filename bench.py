@@ -287,6 +287,112 @@ def time_config(model, x, ts, precision: str, workload: str, batch: int, steps: 
     return r
 
 
+def frontend_configs(model, device, B: int, headline_tiles_per_s: float) -> list:
+    """SURVEY.md section 8(f) rows N1 and N3, timed with the headline's discipline (inputs resident in HBM, warm-up, device
+    synchronisation on both sides of the timed region):
+      (a) N1  wm_preprocess_u8_resized: 16 resident 3648 x 5472 uint8 frames (the val set's size) -> PIL-bilinear resize to
+              512 x 768 -> ToTensor -> Normalize -> zero-padded 1024 x 1024 fp32 tiles; algorithmic bytes per frame = the
+              frame read once + the tile written once;
+      (b) N3  tiling.detect_frame on one resident 6000 x 4000 frame (7 x 5 overlapping tiles): frames/s and the split
+              tile cut / path / merge NMS (each stage timed alone);
+      (c) the chain frames -> N1 -> path -> records at the headline batch: what the input side costs a step."""
+    from wildlifemapper_amd import preprocess, tiling
+    from wildlifemapper_amd.engine import split_records
+    out = []
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / reps, r
+
+    with torch.no_grad():
+        # (a) N1
+        h, w = 3648, 5472
+        torch.manual_seed(7)
+        frames = torch.randint(0, 256, (B, h, w, 3), dtype=torch.uint8, device=device)
+        oh, ow = preprocess.resized_size(h, w, 768, 768)
+        dt, tiles = timed(lambda: preprocess.tiles_from_u8(frames, resize=(768, 768)), 2, 10)
+        bytes_frame = h * w * 3 + 3 * 1024 * 1024 * 4
+        out.append({"config": "SURVEY 8(f) N1: wm_preprocess_u8_resized, %d resident %dx%d uint8 frames -> %dx%d content on 1024x1024 fp32 tiles" % (B, h, w, oh, ow),
+                    "frames": B, "us_per_frame": round(dt / B * 1e6, 1), "frames_per_s": round(B / dt, 1),
+                    "algorithmic_bytes_per_frame": bytes_frame, "algorithmic_gbps": round(bytes_frame * B / dt / 1e9, 1),
+                    "frac_of_8TBps": round(bytes_frame * B / dt / 8e12, 4), "bound": "hbm",
+                    "share_of_a_step_at_headline_rate": round((dt / B) * headline_tiles_per_s, 4)})
+        # (c) chain: frames -> tiles -> path -> records
+        ts = torch.full((B, 2), 1024.0, device=device)
+
+        def chain():
+            return model.detect(preprocess.tiles_from_u8(frames, resize=(768, 768)), ts)["records"]
+        dtc, _ = timed(chain, 2, 5)
+        out.append({"config": "frames -> N1 -> full path -> records, batch=%d (the input side inside the step)" % B,
+                    "tiles_per_s": round(B / dtc, 3), "ms_per_step": round(dtc * 1e3, 3),
+                    "vs_headline_resident_tiles": round((B / dtc) / headline_tiles_per_s, 4),
+                    "note": "content is a 512 x 768 image on a zero canvas, as the val pipeline feeds the model (dataloader_coco.py:288); the path's time does not depend on content"})
+        del frames, tiles
+        # (b) N3
+        H, W = 4000, 6000
+        frame = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device=device)
+        org = torch.tensor(tiling.tile_origins(H, W, 1024, 128), dtype=torch.int32, device=device)
+        n = int(org.shape[0])
+        dt_all, det = timed(lambda: tiling.detect_frame(model, frame, batch=B), 1, 3)
+        dt_cut, xt = timed(lambda: tiling.frame_to_tiles(frame, org), 2, 10)
+        def path():
+            return torch.cat([model.detect(xt[i:i + B])["records"] for i in range(0, n, B)], dim=0)
+        dt_path, rec = timed(path, 1, 3)
+        dt_merge, _ = timed(lambda: tiling.merge_tile_records(rec, org, 0.4), 2, 10)
+        cut_bytes = H * W * 3 + n * 3 * 1024 * 1024 * 4
+        out.append({"config": "SURVEY 8(f) N3: tiling.detect_frame, one resident %dx%d uint8 frame -> %d overlapping 1024x1024 tiles (batches of %d) -> merge NMS" % (W, H, n, B),
+                    "frames_per_s": round(1.0 / dt_all, 3), "ms_per_frame": round(dt_all * 1e3, 2), "tiles_per_frame": n,
+                    "tiles_per_s": round(n / dt_all, 2),
+                    "split_ms": {"tile_cut": round(dt_cut * 1e3, 3), "path": round(dt_path * 1e3, 2), "merge_nms": round(dt_merge * 1e3, 3)},
+                    "tile_cut_algorithmic_gbps": round(cut_bytes / dt_cut / 1e9, 1), "tile_cut_frac_of_8TBps": round(cut_bytes / dt_cut / 8e12, 4),
+                    "merged_detections": int(det["scores"].numel()),
+                    "note": "35 tiles = batches of 16 + 16 + 3: the last batch runs the small-batch kernel instances"})
+    return out
+
+
+def _committed_profile(a, B: int, hub):
+    """Counter-derived numbers of the dominant kernel class from the rocprofv3 --pmc passes committed under profiles/ (newest
+    round first).  Used only for the workload they were collected on; every value is labelled with its file."""
+    if not (a.model == "vit_h" and a.workload == "full"):
+        return None
+    prof = os.path.join(ROOT, "profiles")
+    for tag in ("r4_final", "r3_final", "r3"):
+        tname = f"{tag}_{a.precision}_pmc_traffic.json"
+        try:
+            with open(os.path.join(prof, tname)) as f:
+                t = json.load(f)
+            if int(t.get("batch", 4)) != B or t.get("precision", "bf16") != a.precision:
+                continue
+            out = {"traffic_file": tname, "collected": t.get("collected", "see git log of the file"),
+                   "hbm_bytes_per_launch": t["classes"]["gemm16"]["hbm_bytes_per_launch"],
+                   "caveat": "counters from the builder's box under the profiler's clock; only the division by the live launch time uses this run"}
+            uname = tname.replace("pmc_traffic.json", "pmc_util.txt")
+            try:
+                sect, vals = None, {}
+                for ln in open(os.path.join(prof, uname)):
+                    if ln.startswith("=="):
+                        sect = ln.split()[1]
+                    elif sect in ("gemm16v5_kernel", "gemm8_kernel") and "avg=" in ln:
+                        vals.setdefault(sect, {})[ln.split()[0]] = float(ln.split("avg=")[1])
+                v = vals.get("gemm8_kernel" if a.precision == "fp8" else "gemm16v5_kernel")
+                if v and v.get("GRBM_GUI_ACTIVE"):
+                    out["mfma_busy_pct"] = round(100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * 128.0), 1)
+                    out["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128 SIMDs per XCD), tools/pmc_kernel.py"
+                    out["util_file"] = uname
+            except OSError:
+                pass
+            return out
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 def _config_name(a, B: int, world: int) -> str:
     """Which BASELINE.json config this run is, derived from what actually runs."""
     if a.model != "vit_h":
@@ -394,67 +500,41 @@ def main() -> None:
             g = st["gemm16"]
             achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
             peak = PEAK_TFLOPS[a.precision if a.precision in PEAK_TFLOPS else "bf16"]
-            traffic = None
-            traffic_src = None
-            try:   # HBM bytes per GEMM launch from the PMC passes committed under profiles/ (collected offline with rocprofv3)
-                folded = bool(hub.fold_ln) and a.precision == "fp16"       # the default path: its own counter files
-                final_tree = folded or (a.precision in ("bf16", "fp8") and not hub.fold_ln == "all")     # collected with these defaults
-                for name in ((f"r3_final_{a.precision}_pmc_traffic.json" if final_tree else f"r3_{a.precision}_pmc_traffic.json"),
-                             ("r2_pmc_traffic.json" if a.precision == "bf16" else f"r2_{a.precision}_pmc_traffic.json"),
-                             "r1g_pmc_traffic.json"):   # newest round first; bf16 keeps its round-2 file name
-                    if not os.path.exists(os.path.join(ROOT, "profiles", name)):
-                        continue
-                    with open(os.path.join(ROOT, "profiles", name)) as f:
-                        t = json.load(f)
-                    # the committed counters belong to one workload: use them only for that one
-                    if a.model == "vit_h" and a.workload == "full" and int(t.get("batch", 4)) == B and t.get("precision", "bf16") == a.precision:
-                        traffic = t["classes"]["gemm16"]["hbm_bytes_per_launch"]
-                        traffic_src = name
-                        break
-            except Exception:
-                traffic = None
-            # north_star: "rocprof-reported MFMA utilisation and HBM GB/s against gfx950 peak" for the dominant kernel.  HBM GB/s = the
-            # committed PMC bytes per launch / the live HIP-event launch time; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x
-            # 128 SIMDs per XCD) from the committed counter pass of the same workload (profiles/<round>_pmc_util.txt).
+            # Live numbers (this run, HIP events on the launch stream): achieved, frac, avg_launch_us, launches, FLOPs and the
+            # ALGORITHMIC bytes per launch (operands + residual + outputs as the launcher's byte model counts them).
+            # Counter-derived numbers come from rocprofv3 --pmc passes committed under profiles/ (another box, another day):
+            # they sit under `from_committed_profile` with their file names; `traffic` (the contract's key) repeats the PMC bytes
+            # per launch of that file and `traffic_source` says so.
             avg_launch_s = g["ms"] * 1e-3 / max(g["launches"], 1)
-            hbm_gbps = round(traffic / avg_launch_s / 1e9, 1) if traffic and avg_launch_s > 0 else None
-            mfma_busy = None
-            mfma_src = None
-            try:
-                util = traffic_src.replace("pmc_traffic.json", "pmc_util.txt") if traffic_src else None
-                if util:
-                    sect, vals = None, {}
-                    for ln in open(os.path.join(ROOT, "profiles", util)):
-                        if ln.startswith("=="):
-                            sect = ln.split()[1]
-                        elif sect in ("gemm16v5_kernel", "gemm8_kernel") and "avg=" in ln:
-                            vals.setdefault(sect, {})[ln.split()[0]] = float(ln.split("avg=")[1])
-                    v = vals.get("gemm8_kernel" if a.precision == "fp8" else "gemm16v5_kernel")
-                    if v and v.get("GRBM_GUI_ACTIVE"):
-                        mfma_busy = round(100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * 128.0), 1)
-                        mfma_src = util
-            except Exception:
-                mfma_busy = None
+            alg_bytes = g["bytes"] / max(g["launches"], 1)
+            committed = _committed_profile(a, B, hub)
+            traffic = committed["hbm_bytes_per_launch"] if committed else None
+            if committed:
+                committed["hbm_gbps_at_live_launch_time"] = round(traffic / avg_launch_s / 1e9, 1) if avg_launch_s > 0 else None
+                committed["hbm_frac_of_8TBps"] = round(committed["hbm_gbps_at_live_launch_time"] / 8000.0, 4) if committed["hbm_gbps_at_live_launch_time"] else None
+                committed["traffic_over_algorithmic"] = round(traffic / alg_bytes, 3) if alg_bytes > 0 else None
+            folded = (bool(hub.fold_ln) and a.precision == "fp16") or (hub.fold_ln == "all" and a.precision == "bf16")
             roofline = {"bound": "mfma", "kernel": ("gemm8_kernel (fp8 block-scaled MFMA, the blocks' 4 projections) + the stem / neck fp16 GEMMs" if a.precision == "fp8"
                                                     else "gemm16v5_kernel<T,320|256,3> (all 16-bit MFMA GEMM launches)"),
-                        "folded_layernorm": bool(hub.fold_ln) and a.precision == "fp16" or hub.fold_ln == "all" and a.precision == "bf16",
-                        "note": ("with the folded LayerNorm (default, fp16 operands) the GEMM launches also carry the blocks' LayerNorms -- row statistics and a "
-                                 "16-bit copy of the stream in the residual GEMMs' epilogues, the normalisation in the qkv / lin1 epilogues -- so their "
-                                 "time rises by ~3 ms per step while the LayerNorm class drops by ~6 ms: tiles/s up 2.6 %, this fraction down ~0.02; "
-                                 "other_configs holds the same step with the LayerNorm as its own kernel") if a.precision == "fp16" and hub.fold_ln else None,
-                        "achieved": round(achieved, 2), "peak": peak,
-                        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                        "traffic_note": f"HBM bytes/launch, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/{traffic_src} (tools/pmc_summarize.py)" if traffic_src else None,
-                        "hbm_gbps": hbm_gbps, "hbm_peak_gbps": 8000.0, "hbm_frac": round(hbm_gbps / 8000.0, 4) if hbm_gbps else None,
-                        "mfma_busy_pct": mfma_busy,
-                        "mfma_busy_note": (f"matrix pipe busy cycles / (GPU-active cycles x SIMDs), rocprofv3 --pmc pass under the profiler's clock, "
-                                           f"profiles/{mfma_src} (tools/pmc_kernel.py)") if mfma_src else None,
+                        "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        "traffic": traffic,
+                        "traffic_source": (f"NOT measured in this run: rocprofv3 PMC pass committed as profiles/{committed['traffic_file']} "
+                                           f"(FETCH_SIZE x 2 + WRITE_SIZE per launch, tools/pmc_summarize.py)") if committed else None,
+                        "measured_live": "achieved, frac, avg_launch_us, launches_per_step, gflop_per_launch, ms_per_step_with_events: HIP events on the launch stream, this run",
+                        "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
                         "launches_per_step": g["launches"] // a.steps,
                         "gflop_per_launch": round(g["flops"] / max(g["launches"], 1) / 1e9, 3),
-                        "avg_launch_us": round(g["ms"] * 1e3 / max(g["launches"], 1), 2),
+                        "algorithmic_bytes_per_launch": round(alg_bytes),
+                        "algorithmic_bytes_note": "operands (A, W: 2 B per element), residual and outputs per launch as the launchers count them (csrc/wm_api.hip Bracket), averaged over the class",
+                        "algorithmic_gbps": round(alg_bytes / avg_launch_s / 1e9, 1) if avg_launch_s > 0 else None,
                         "ms_per_step_with_events": round(prof_elapsed / a.steps * 1e3, 3),
-                        "sustained_clock_note": "power-limited: in-kernel s_memtime / wall clock (WM_GEMM_DBG=1 / WM_GEMM8_DBG=1) reads ~1.5 GHz "
-                                                "at the 31st bf16 GEMM of a step (1.79 GHz isolated) and 1.6-1.9 GHz in the fp8 GEMM; "
+                        "from_committed_profile": committed,
+                        "folded_layernorm": folded,
+                        "note": ("with the folded LayerNorm (default) the GEMM launches also carry the blocks' LayerNorms -- row statistics and the 16-bit "
+                                 "plane(s) of the stream in the residual GEMMs' epilogues, the normalisation in the qkv / lin1 epilogues; "
+                                 "other_configs holds the same step with the LayerNorm as its own kernel") if folded else None,
+                        "sustained_clock_note": "power-limited: in-kernel s_memtime / wall clock (dev build, WM_GEMM_DBG=1) reads ~1.5 GHz "
+                                                "at the 31st 16-bit GEMM of a step (1.79 GHz isolated) and 1.6-1.9 GHz in the fp8 GEMM; "
                                                 "DESIGN.md section 5",
                         "gemm_instances_per_step": gemm_instances}
             classes = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["launches"] // a.steps,
@@ -497,7 +577,11 @@ def main() -> None:
             try:
                 others.append(dict(time_config(model, x, ts, "bf16", "encoder", 4, 5, 2, device), config="BASELINE.json configs[1]: ViT-H encoder bf16, batch=4"))
                 if B >= 16:
-                    others.append(dict(time_config(model, x, ts, "bf16", "full", 16, 5, 2, device, gemm_rate=True), config="configs[2] with bf16 operands (LayerNorm as its own kernel)"))
+                    others.append(dict(time_config(model, x, ts, "bf16", "full", 16, 5, 2, device, fold_ln=fold_default, gemm_rate=True),
+                                       config="configs[2] with bf16 operands (bf16 default: LayerNorm as its own kernel, fp32 residual stream)"))
+                    others.append(dict(time_config(model, x, ts, "bf16", "full", 16, 5, 2, device, fold_ln="all", gemm_rate=True),
+                                       config="configs[2] with bf16 operands, LayerNorm folded + split residual stream (WM_LN_FOLD=2, opt-in: another draw of bf16's "
+                                              "~1e-3 logits error, include/wm_hip.h WM_CFG_FOLD_LN)"))
                     others.append(dict(time_config(model, x, ts, "fp16", "full", 16, 5, 2, device, fold_ln=False, gemm_rate=True),
                                        config="configs[2], fp16 operands, LayerNorm as its own kernel (WM_LN_FOLD=0): the GEMM class without the folded "
                                               "LayerNorm's statistics / 16-bit-copy / normalisation work in its epilogues"))
@@ -514,6 +598,9 @@ def main() -> None:
                     hub.fold_ln = fold_default
                     hub.close()
             line["other_configs"] = others
+        # the rows either side of the path (N1 input pipeline, N3 large-frame tiling), measured
+        if world == 1 and a.model == "vit_h" and a.workload == "full" and not a.no_other_configs and B >= 4:
+            line["frontend_configs"] = frontend_configs(model, device, B, tiles_per_s)
         if not a.no_cpu_baseline and world == 1 and a.workload == "full":
             line["cpu_baseline"], line["map_vs_cpu_ref"] = cpu_baseline(a.model, sd, model, device, x, ts, first, {k: v.cpu() for k, v in out_batch.items()})
         else:

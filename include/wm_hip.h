@@ -34,7 +34,7 @@ extern "C" {
  * wm_profile_read no longer reports the fused-LayerNorm time-out (wm_forward / wm_encoder_forward do); precision value 2
  * (fp8), WM_FLAG_MERGED and a NULL handle in wm_postprocess_nms date from round 2.  The Python binding refuses a library
  * whose wm_abi_version() differs from the value it was written for. */
-#define WM_ABI_VERSION 3
+#define WM_ABI_VERSION 4
 
 /* operand type of the transformer blocks' MFMA GEMMs / attention (accumulation, residual stream, LayerNorm
  * statistics, softmax and the whole decoder are fp32; the stem, the HFC adaptor and the neck -- 2.9 % of the
@@ -82,9 +82,12 @@ typedef struct wm_config {
  * stream is not re-read by a LayerNorm kernel.  Results differ from the unfolded path within the operand rounding (the
  * rounding points move), they do not depend on the batch size.  The Python drop-in
  * sets it by default (WM_LN_FOLD=0 turns it off): +2.6 % tiles/s (ViT-H, B = 16), logits 2.3e-4 against 2.4e-4 unfolded.
- * It covers the blocks whose operands are fp16.  bf16-operand blocks keep their LayerNorm kernel unless
- * WM_CFG_FOLD_LN_BF16 is set as well: the folded weight gamma (.) W is rounded a second time, and with bf16's 8-bit mantissa
- * that costs the logits 15-25 % more error (ViT-L 9.3e-4 -> 1.15e-3, ViT-H 8.2e-4 -> 9.5e-4), which bf16 cannot afford. */
+ * gamma (.) W is computed from the fp32 weight (kept on the device) and rounded once (round 3 folded from the 16-bit weight).
+ * It covers the blocks whose operands are fp16 (measured on five ViT-H tiles: logits 1.8-1.9e-4 folded, 2.3-2.4e-4 unfolded).
+ * bf16-operand blocks keep their LayerNorm kernel unless WM_CFG_FOLD_LN_BF16 is set as well: with 8-bit mantissas the logits
+ * error sits at ~1e-3 and every change of a rounding point is another draw from that distribution -- measured in round 4 with
+ * gamma (.) W rounded once: ViT-H 1.29-1.36e-3 (LayerNorm kernel: 7.5-8.0e-4), ViT-L 8.2e-4 (9.3e-4); parity first, so the
+ * mode that holds 1e-3 on both fixtures stays the default for bf16 and the faster folded form (+3.6 % tiles/s) is opt-in. */
 #define WM_CFG_FOLD_LN 2
 #define WM_CFG_FOLD_LN_BF16 4
 
@@ -237,7 +240,9 @@ int wm_profile_read(wm_handle* h, wm_kclass_stat* out /* [WM_KCLASS_COUNT] */);
 #define WM_GEMM_FP8_256 12      /* gemm8_kernel<256> */
 #define WM_GEMM_V5_320_FOLDP 13 /* gemm16v5_kernel<320> fp32 + residual + row statistics + 16-bit copy (folded LayerNorm, producer) */
 #define WM_GEMM_V5_256_FOLDP 14
-#define WM_GEMM_VARIANT_COUNT 15
+#define WM_GEMM_V5_320_SPLIT 15 /* gemm16v5_kernel<320> split-stream producer: residual planes (hi, lo) in and out, row statistics (round 4) */
+#define WM_GEMM_V5_256_SPLIT 16
+#define WM_GEMM_VARIANT_COUNT 17
 int wm_debug_gemm_variant_counts(int64_t* out /* [WM_GEMM_VARIANT_COUNT] */, int n);
 int wm_debug_reset_gemm_variant_counts(void);
 
@@ -248,6 +253,12 @@ int wm_debug_reset_gemm_variant_counts(void);
  * packed qkv, the attention output, the GELU hidden, the 16-bit copy of the last block's output.  A non-zero count
  * means clamped operands: switch that checkpoint to WM_PREC_BF16 (no clamp, 8-bit mantissa).  Costs one streaming read of
  * each buffer; off by default and absent from timed runs. */
+/* Always on (round 4): the producers of the residual stream's fp16 plane (residual GEMM epilogues, the standalone statistics
+ * kernel) set a host-visible word when a stream value reaches the fp16 clamp (|x| >= 65504).  wm_stream_overflow returns 1 if
+ * that happened since the last reset (kernels that have finished; no synchronisation), 0 otherwise.  The Python drop-in checks
+ * it at every call and warns once: such a checkpoint should run with WM_PREC_BF16. */
+int wm_stream_overflow(wm_handle* h, int reset);
+
 #define WM_SAT_LN 0
 #define WM_SAT_QKV 1
 #define WM_SAT_ATTN 2
@@ -302,6 +313,21 @@ int wm_op_gemm16_folded(const void* x16_dev, const void* wf_dev, const float* c1
 int wm_op_gemm16_stats(const void* a_dev, const void* w_dev, const float* bias_dev, const float* residual_dev, float* out_f32_dev,
                        void* x16_dev, float* stats_dev, int M, int N, int K, int layout, int precision, void* stream);
 int wm_op_pack16(const void* in_dev, void* out_dev, int64_t rows, int K, void* stream);
+int wm_op_unpack16(const void* in_dev, void* out_dev, int64_t rows, int K, void* stream);     /* the inverse: LDS-image order -> row-major */
+
+/* Split residual stream (round 4; csrc/gemm16_v5.h "Split stream").  The blocks' residual stream x is kept as two 16-bit planes
+ * in LDS-image order: hi = round16(x) in the block's operand type (it IS the folded LayerNorm's operand) and lo = fp16(x - hi);
+ * x = hi + lo carries 22 (fp16) / 19 (bf16) significant bits, and a residual GEMM's epilogue moves 8 instead of 10 bytes per element.
+ * wm_op_ln_stats16_split: as wm_op_ln_stats16, also writing lo and, with x_rw_dev (may alias x_dev), the fp32 rows rounded to
+ *   float(hi) + float(lo): what a small call (fp32 stream) does so that its bits equal a large call's (split stream).
+ * wm_op_gemm16_split: (hi, lo) += a w^T + bias, in place: v = (acc + bias) + (float(hi) + float(lo)), statistics of v as
+ *   wm_op_gemm16_stats writes them, hi' = round16(v), lo' = fp16(v - hi').  `layout`: WM_GEMM_W_PACKED | WM_GEMM_A_PACKED.
+ * wm_op_stream_merge: out[rows][C] fp32 = float(hi) + float(lo). */
+int wm_op_ln_stats16_split(const float* x_dev, float* stats_dev, void* hi_dev, void* lo_dev, float* x_rw_dev, int64_t rows, int C,
+                           int precision, void* stream);
+int wm_op_gemm16_split(const void* a_dev, const void* w_dev, const float* bias_dev, void* hi_dev, void* lo_dev, float* stats_dev,
+                       int M, int N, int K, int layout, int precision, void* stream);
+int wm_op_stream_merge(const void* hi_dev, const void* lo_dev, float* out_dev, int64_t rows, int C, int precision, void* stream);
 
 /* fp8 (OCP e4m3) GEMM of WM_PREC_FP8, gemm8.h: C = act((A W^T) * wscale[n] + bias[n]) (+ residual).
  * a [M,K] e4m3 (unit scale), w [N,K] e4m3, wscale [N] fp32; exactly one of: residual + out_f32 (+ out_16), out_8 (e4m3),

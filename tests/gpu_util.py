@@ -123,6 +123,43 @@ def gemm16_stats(a16, w16, bias, residual, prec="fp16", layout=0):
     return out, x16, stats
 
 
+def ln_stats16_split(x, prec="fp16", rewrite=True):
+    """Split stream, standalone producer: (stats, hi, lo in LDS-image order, x rounded to float(hi) + float(lo))."""
+    code, dt = PRECS[prec]
+    rows, Cc = x.shape
+    stats = torch.empty((rows, Cc // fold_bn(Cc), 2), device=x.device, dtype=torch.float32)
+    hi = torch.empty((rows, Cc), device=x.device, dtype=dt)
+    lo = torch.empty((rows, Cc), device=x.device, dtype=torch.float16)
+    xr = x.clone() if rewrite else None
+    N.check(N.lib().wm_op_ln_stats16_split(N.ptr(x), N.ptr(stats), N.ptr(hi), N.ptr(lo), N.ptr(xr), rows, Cc, code, sp()))
+    return stats, hi, lo, xr
+
+
+def gemm16_split(a16, w16, bias, hi, lo, prec="fp16", layout=0):
+    """Split stream, producing GEMM, in place on clones: (hi', lo', stats) with hi' + lo' = (hi + lo) + a w^T + bias."""
+    code, dt = PRECS[prec]
+    M, K = a16.shape
+    Nn = w16.shape[0]
+    hi2, lo2 = hi.clone(), lo.clone()
+    stats = torch.empty((M, Nn // fold_bn(Nn), 2), device=a16.device, dtype=torch.float32)
+    N.check(N.lib().wm_op_gemm16_split(N.ptr(a16), N.ptr(w16), N.ptr(bias), N.ptr(hi2), N.ptr(lo2), N.ptr(stats), M, Nn, K, layout, code, sp()))
+    return hi2, lo2, stats
+
+
+def stream_merge(hi, lo, prec="fp16"):
+    code, dt = PRECS[prec]
+    rows, Cc = hi.shape
+    out = torch.empty((rows, Cc), device=hi.device, dtype=torch.float32)
+    N.check(N.lib().wm_op_stream_merge(N.ptr(hi), N.ptr(lo), N.ptr(out), rows, Cc, code, sp()))
+    return out
+
+
+def unpack16(t: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(t)
+    N.check(N.lib().wm_op_unpack16(N.ptr(t.contiguous()), N.ptr(out), t.shape[0], t.shape[1], sp()))
+    return out
+
+
 def gemm32(a, w, bias=None, residual=None, act=0):
     M, K = a.shape
     Nn = w.shape[0]

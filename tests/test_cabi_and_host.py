@@ -49,7 +49,8 @@ def test_weight_watch_notices_every_kind_of_change():
     hub = m._hub
     assert not hub._unchanged()                      # nothing watched yet: full walk
     hub._rebuild_watch()
-    assert hub._unchanged() and len(hub._watch) == len(list(hub._named_tensors()))
+    n_tensors = sum(1 for w in hub._watch if w[3] is not None)
+    assert hub._unchanged() and n_tensors == len(list(hub._named_tensors()))
     with torch.no_grad():
         m.image_encoder.blocks[3].attn.qkv.weight.mul_(1.0)
     assert not hub._unchanged()
@@ -63,6 +64,31 @@ def test_weight_watch_notices_every_kind_of_change():
     assert hub._unchanged()
     hub.invalidate()
     assert not hub._unchanged()
+    # a whole sub-module swapped: the old module's parameter dicts are untouched, the parent's slot is not
+    import copy
+    hub._rebuild_watch()
+    assert hub._unchanged()
+    m.image_encoder.blocks[2] = copy.deepcopy(m.image_encoder.blocks[2])
+    assert not hub._unchanged()
+    hub._rebuild_watch()
+    m.image_encoder.neck[1] = copy.deepcopy(m.image_encoder.neck[1])
+    assert not hub._unchanged()
+    # register / adopt after a forward drop the watch list
+    hub._rebuild_watch()
+    assert hub._unchanged()
+    hub.register("extra.", torch.nn.Linear(2, 2))
+    assert not hub._unchanged()
+    del hub._sources["extra."]
+    hub._rebuild_watch()
+    from wildlifemapper_amd.engine import hub_for
+    other = hub_for("vit_b")
+    hub.adopt(other)
+    assert not hub._unchanged()
+    # documented limit: a write through .data does not move the version counter -> invalidate() is the contract
+    hub._rebuild_watch()
+    with torch.no_grad():
+        m.image_encoder.blocks[3].attn.qkv.weight.data.add_(0.0)
+    assert hub._unchanged()
 
 
 def test_struct_layouts_match_header():

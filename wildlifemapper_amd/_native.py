@@ -17,12 +17,12 @@ PREC_BY_NAME = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "fp8": P
 NUM_QUERIES, NUM_LOGITS = 51, 8
 KCLASS_NAMES = ("gemm16", "attn_window", "attn_global", "layernorm", "other")
 GEMM_VARIANTS = ("v1_128", "v2_160", "v2_128", "v3_lockstep", "v3_conv3x3", "v5_320", "v5_320_res", "v5_256", "v5_256_res",
-                 "v5_320_lnf", "v5_256_lnf", "fp8_320", "fp8_256", "v5_320_foldp", "v5_256_foldp")
+                 "v5_320_lnf", "v5_256_lnf", "fp8_320", "fp8_256", "v5_320_foldp", "v5_256_foldp", "v5_320_split", "v5_256_split")
 FLAG_CONF, FLAG_SCORE, FLAG_NMS, FLAG_MERGED = 1, 2, 4, 8
 CFG_FUSE_LN = 1
 CFG_FOLD_LN = 2
 CFG_FOLD_LN_BF16 = 4
-ABI_VERSION = 3            # include/wm_hip.h WM_ABI_VERSION this binding was written for
+ABI_VERSION = 4            # include/wm_hip.h WM_ABI_VERSION this binding was written for
 FP8_QKV, FP8_PROJ, FP8_MLP, FP8_ALL = 1, 2, 4, 7
 GEMM_W_PACKED, GEMM_A_PACKED, GEMM_OUT_PACKED, LAYOUT_PACKED = 0x1000, 0x2000, 0x4000, 0x100
 SAT_NAMES = ("layernorm_out", "qkv", "attention_out", "mlp_hidden", "last_block_16")
@@ -78,6 +78,11 @@ SYMBOLS = {
     "wm_op_gemm16_takes_packed": (_I, [_I, _I, _I]),
     "wm_op_pack16": (_I, [_P, _P, _L, _I, _P]),
     "wm_op_ln_stats16": (_I, [_P, _P, _P, _L, _I, _I, _P]),
+    "wm_op_ln_stats16_split": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "wm_op_gemm16_split": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm_op_stream_merge": (_I, [_P, _P, _P, _L, _I, _I, _P]),
+    "wm_op_unpack16": (_I, [_P, _P, _L, _I, _P]),
+    "wm_stream_overflow": (_I, [_P, _I]),
     "wm_op_fold_weight16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "wm_op_gemm16_folded": (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P]),
     "wm_op_gemm16_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

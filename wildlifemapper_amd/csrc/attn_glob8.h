@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
         char* sTab = sKV;
         float* sT = (float*)smem + wave * L::WAVE_F;          // [query c][65] fp32 staging
         // both tables staged at once (the K / V ring is idle and holds them side by side), one barrier pair
-        static_assert(3 * L::TILE >= 256 * G::KS, "both rel-pos table images are staged in the K / V ring");
+        static_assert(2 * L::TILE >= 256 * G::KS, "both rel-pos table images are staged in ring slots 0-1 (tile 0 is DMA'd into slot 2 before they are read)");
         __syncthreads();
         {   // all of a thread's table chunks are requested before the first is converted (as a rolled loop each load was waited for
             // in turn: ~12k cycles of the prologue in the timeline)

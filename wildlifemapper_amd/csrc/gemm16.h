@@ -60,6 +60,15 @@ struct Gemm16Args {
     const float* fold_c1;
     int fold_ntile;
     float fold_bn, fold_eps;
+    // Split residual stream (gemm16_v5.h "Split stream", round 4): the stream x as two 16-bit planes in LDS-image order,
+    // hi = T(x) (the folded LayerNorm's operand) and lo = fp16(x - hi).  SPLIT instance: the residual comes in as
+    // (res_hi, res_lo) and leaves as (out16 = hi, out_lo); the FOLDP instance (fp32 residual in) writes out_lo too when it is
+    // given and then skips out32 when that is null.  overflow: a host-visible word the producers set to 1 when a value of the
+    // stream reaches the fp16 clamp (|x| >= 65504), or null.
+    const u16* res_hi;
+    const u16* res_lo;
+    u16* out_lo;
+    int* overflow;
 };
 
 template <class T>

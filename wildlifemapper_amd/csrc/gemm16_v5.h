@@ -63,9 +63,19 @@ namespace wm {
 // included); fp16's range holds for |x| < 65504 (the saturation census watches this buffer).
 // (FOLDC, the consumer, is an instance of its own: compiled into the plain instance its extra epilogue state cost that kernel
 // 114 spilled registers.)
-template <class T, int BN, int NSLOT = 3, bool DBG = false, bool FOLDP = false, bool FOLDC = false>
+//
+// Split stream (round 4).  The FOLDP epilogue moved 10 bytes per element (fp32 residual in, fp32 out, 16-bit copy out) with every
+// CU in the same phase: it is bound by the memory system (proj at 0.31 of peak).  The stream is therefore kept as TWO 16-bit
+// planes in LDS-image order, hi = T(x) and lo = fp16(x - hi): x = hi + lo carries 22 (fp16 hi) / 19 (bf16 hi) significant bits,
+// the hi plane IS the folded LayerNorm's operand, and the SPLIT instance's epilogue reads 4 and writes 4 bytes per element: per
+// pass 2 planes x 2 strips of 16 rows x BN columns = 4 BN / 32 one-KiB pieces by LDS-DMA (the same piece count as the fp32
+// tile), v = (acc + bias) + (float(hi) + float(lo)), statistics from v as before, hi' = T(v), lo' = fp16(v - hi').  In place:
+// a workgroup reads its own tile's planes before it writes them.  Where a residual GEMM is a half-width launch (1-2 tiles per
+// call) the stream stays fp32 and ln_stats_x16_kernel rounds it to hi + lo in place, so a tile's bits do not depend on the batch.
+template <class T, int BN, int NSLOT = 3, bool DBG = false, bool FOLDP = false, bool FOLDC = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
     static_assert(!(FOLDC && (FOLDP || DBG)), "the folded-LayerNorm consumer is the plain 16-bit-output kernel");
+    static_assert(!SPLIT || FOLDP, "the split-stream epilogue is a form of the statistics-producing one");
     using C = G3<BN, 4>;
     constexpr int AHEAD = NSLOT - 1;                       // K-steps of DMA in flight
     // timing experiments of tools/gemm_bench.py (--act 256 / 512 / 1024): compiled in only with -DWM_GEMM_TIMING_BITS=1
@@ -190,8 +200,21 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
                   "epilogue LDS map");
     const int res_mod = p.res_mod > 0 ? p.res_mod : p.M;
     const bool res_wrap = res_mod != p.M;                           // broadcast residual (pos_embed): row m % res_mod
+    constexpr int SP_KT = BN / 32;                                 // split stream: pieces per 16-row strip and plane
+    static_assert(4 * SP_KT == C::WAVES * RP_PW, "split-stream pieces per pass = the fp32 tile's");
     auto res_dma = [&](int q) {
         char* dst = smem + ((q & 1) ? RES_L1 : RES_L0);
+        if constexpr (SPLIT) {
+            // piece idx: plane (hi | lo) x strip (rows q*16.. of the upper | lower 128) x kt; a piece is 1 KiB contiguous in memory
+#pragma unroll
+            for (int i = 0; i < RP_PW; ++i) {
+                const int idx = wave * RP_PW + i;
+                const int plane = idx / (2 * SP_KT), strip = (idx / SP_KT) & 1, kt = idx % SP_KT;
+                const char* src = (const char*)(plane ? p.res_lo : p.res_hi);
+                const char* base = sgpr_ptr(src + ((size_t)((m0 + strip * 128 + q * 16) >> 4) * (size_t)(p.N >> 5) + (size_t)((n0 >> 5) + kt)) * 1024);
+                __builtin_amdgcn_global_load_lds(base + (unsigned)lane * 16u, WM_LDS_PTR(dst + idx * 1024), 16, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < RP_PW; ++i) {
             const int piece = wave * RP_PW + i;
@@ -200,13 +223,14 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             if (res_wrap) m %= res_mod;
             __builtin_amdgcn_global_load_lds((const char*)(p.residual + (size_t)m * p.N + n0 + ch * 4), WM_LDS_PTR(dst + piece * 1024), 16, 0, 0);
         }
+        }
     };
 
 #pragma unroll
     for (int i = 0; i < C::MT; ++i)
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.residual) res_dma(0);
+    if (SPLIT || p.residual) res_dma(0);
     // landing buffer 0 is idle without a residual: raw partials (8 KiB), (mean, rstd) per row (2 KiB), c1 | c2 of the tile's columns
     constexpr int FOLD_RAW = LDS_TOTAL - RES_BYTES, FOLD_MR = FOLD_RAW + 8192, FOLD_C = FOLD_MR + 2048;
     static_assert(FOLD_C + 2 * BN * 4 <= LDS_TOTAL, "fold LDS map");
@@ -345,22 +369,45 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
             const char* land = smem + ((q & 1) ? RES_L1 : RES_L0);
             const int m = m0 + (r >> 4) * 128 + q * 16 + (r & 15);
             f32x4 v[CPT];
+            float amax = 0.f;
 #pragma unroll
             for (int kk = 0; kk < CPT; ++kk) {
                 const int ch = l16 + 16 * kk;
-                v[kk] = *(const f32x4*)(smem + RES_STG + r * ROWB + ch * 16) + *(const f32x4*)(land + (r * RP_CPR + ch) * 16);
-                *(f32x4*)(p.out32 + (size_t)m * p.N + n0 + ch * 4) = v[kk];
+                f32x4 res;
+                if constexpr (SPLIT) {
+                    // the landed planes are in LDS-image order: piece (strip, kt), position = row * 4 + swizzled chunk
+                    const int rr = r & 15, kt = ch >> 3, pos = rr * 4 + ((((ch & 7) >> 1)) ^ ((0 - (rr >> 2)) & 3));
+                    const int off = (((r >> 4) * SP_KT + kt) << 10) + pos * 16 + (ch & 1) * 8;
+                    const typename T::vec4 h4 = *(const typename T::vec4*)(land + off);
+                    const f16x4 l4 = *(const f16x4*)(land + 2 * SP_KT * 1024 + off);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) res[j] = T::to_f32(h4[j]) + (float)l4[j];
+                } else {
+                    res = *(const f32x4*)(land + (r * RP_CPR + ch) * 16);
+                }
+                v[kk] = *(const f32x4*)(smem + RES_STG + r * ROWB + ch * 16) + res;
+                if (p.out32) *(f32x4*)(p.out32 + (size_t)m * p.N + n0 + ch * 4) = v[kk];
+                if constexpr (std::is_same<T, FP16>::value) amax = fmaxf(fmaxf(fmaxf(fabsf(v[kk][0]), fabsf(v[kk][1])), fmaxf(fabsf(v[kk][2]), fabsf(v[kk][3]))), amax);
             }
             float mean, m2;
             ln_partial16<CPT>(v, 1.0f / BN, mean, m2);
             if (l16 == 0) *(float2*)(p.st_stats + ((size_t)m * ntile + nt) * 2) = make_float2(mean, m2);
+            if constexpr (std::is_same<T, FP16>::value) {
+                if (amax >= 65504.f && p.overflow) *(volatile int*)p.overflow = 1;     // the fp16 plane clamps: loud on the host side (wm_overflow_count)
+            }
             // a wave holds 4 consecutive rows: per K-step of the copy its 16 lanes x 4 rows write 256 contiguous bytes
 #pragma unroll
             for (int kk = 0; kk < CPT; ++kk) {
                 typename T::vec4 o;
+                f16x4 lo;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[kk][j]);
-                *(typename T::vec4*)(p.out16 + lds_image_index(m, n0 + (l16 + 16 * kk) * 4, p.N)) = o;
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = T::from_f32(v[kk][j]);
+                    lo[j] = FP16::from_f32(v[kk][j] - T::to_f32(o[j]));
+                }
+                const int64_t e = lds_image_index(m, n0 + (l16 + 16 * kk) * 4, p.N);
+                *(typename T::vec4*)(p.out16 + e) = o;
+                if (SPLIT || p.out_lo) *(f16x4*)(p.out_lo + e) = lo;
             }
             if (q + 1 < C::MT) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -503,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void gemm16v5_kernel(Gemm16Args p) {
         }
     }
     };
-    if constexpr (FOLDP) {
+    if constexpr (FOLDP) {                                    // (SPLIT is a form of it)
         epilogue(std::integral_constant<int, ACT_NONE>{}, std::false_type{});
     } else if constexpr (FOLDC) {                            // folded LayerNorm: the 16-bit-output GEMMs qkv (no activation) and lin1 (GELU)
         if (act == ACT_GELU) epilogue(std::integral_constant<int, ACT_GELU>{}, std::true_type{});

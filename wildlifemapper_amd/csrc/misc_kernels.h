@@ -162,28 +162,37 @@ __global__ __launch_bounds__(256) void layernorm_tiled_kernel(const float* __res
     }
 }
 
-// Folded LayerNorm, weight side (once per wm_finalize_weights): from the 16-bit weight W16 [N][K] (row-major, as packed for
-// the classic path), the LayerNorm's gamma / beta [K] and the Linear's bias [N]:
-//   wf[n][k] = round16(gamma[k] * W16[n][k])   written in LDS-image order
-//   c1[n] = sum_k wf[n][k]        c2[n] = sum_k beta[k] * W16[n][k] + bias[n]
+// Folded LayerNorm, weight side (once per wm_finalize_weights): from the weight W [N][K] (row-major), the LayerNorm's
+// gamma / beta [K] and the Linear's bias [N]:
+//   wf[n][k] = round16(gamma[k] * W[n][k])   written in LDS-image order
+//   c1[n] = sum_k wf[n][k]        c2[n] = sum_k beta[k] * W[n][k] + bias[n]
+// W is the fp32 weight when `w32` is given (the engine's path since round 4: the folded weight is then rounded ONCE, which is what
+// lets bf16-operand blocks fold: rounded twice, bf16 cost 8.7-9.5e-4 against 7.2-8.2e-4 on the ViT-H logits), else the 16-bit
+// weight `w16` as packed for the unfolded path (wm_op_fold_weight16: the op-level identity tests against LayerNorm-then-GEMM).
 // One workgroup per output row; fixed summation order (thread-strided partials, then a fixed tree): the same bits every time.
 template <class T>
-__global__ __launch_bounds__(256) void fold_weight_kernel(const u16* __restrict__ w16, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ bias, u16* __restrict__ wf, float* __restrict__ c1,
-                                                          float* __restrict__ c2, int N, int K) {
+__global__ __launch_bounds__(256) void fold_weight_kernel(const u16* __restrict__ w16, const float* __restrict__ w32, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ bias, u16* __restrict__ wf,
+                                                          float* __restrict__ c1, float* __restrict__ c2, int N, int K) {
     const int n = blockIdx.x, tid = threadIdx.x;
     __shared__ float red[2][256];
     float s1 = 0.f, s2 = 0.f;
     for (int k4 = tid; k4 < K / 4; k4 += 256) {
-        const typename T::vec4 w = *(const typename T::vec4*)(w16 + (size_t)n * K + k4 * 4);
+        f32x4 wv;
+        if (w32) {
+            wv = *(const f32x4*)(w32 + (size_t)n * K + k4 * 4);
+        } else {
+            const typename T::vec4 w = *(const typename T::vec4*)(w16 + (size_t)n * K + k4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = T::to_f32(w[j]);
+        }
         const f32x4 g = *(const f32x4*)(gamma + k4 * 4), b = *(const f32x4*)(beta + k4 * 4);
         typename T::vec4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float wv = T::to_f32(w[j]);
-            o[j] = T::from_f32(g[j] * wv);
+            o[j] = T::from_f32(g[j] * wv[j]);
             s1 += T::to_f32(o[j]);
-            s2 = fmaf(b[j], wv, s2);
+            s2 = fmaf(b[j], wv[j], s2);
         }
         *(typename T::vec4*)(wf + lds_image_index(n, k4 * 4, K)) = o;
     }
@@ -200,9 +209,13 @@ __global__ __launch_bounds__(256) void fold_weight_kernel(const u16* __restrict_
 // [rows][C / BN][2] = (mean, M2) -- the same arithmetic, lane assignment and order as the residual GEMM's FOLDP epilogue and
 // as layernorm_tiled_kernel above -- and the 16-bit copy of the rows in LDS-image order.  Used where the residual stream was
 // not produced by a FOLDP launch: a half-width GEMM (one or two tiles per call), or an operand-type boundary between blocks.
+// Split stream (round 4, gemm16_v5.h "Split stream"): with `lo16` the kernel also writes lo = fp16(x - hi) in the same order, and with
+// `x_rw` it rewrites the fp32 rows as float(hi) + float(lo) -- the value the SPLIT GEMM instance reconstructs -- so that the
+// half-width path (fp32 stream) and the split path carry the same stream bit for bit.  overflow: set to 1 when an fp16 hi clamps.
 template <class T, int BN>
 __global__ __launch_bounds__(256) void ln_stats_x16_kernel(const float* __restrict__ x, float* __restrict__ stats, u16* __restrict__ x16,
-                                                           int64_t rows, int C) {
+                                                           int64_t rows, int C, u16* __restrict__ lo16 = nullptr, float* x_rw = nullptr,
+                                                           int* overflow = nullptr) {
     constexpr int CPT = BN / 64;
     const int lane = threadIdx.x & 63, k = lane >> 4, l16 = lane & 15;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -217,12 +230,64 @@ __global__ __launch_bounds__(256) void ln_stats_x16_kernel(const float* __restri
     ln_partial16<CPT>(v, 1.0f / BN, pm, pq);
     if (!live) return;
     if (l16 == 0) *(float2*)(stats + (row * ntile + k) * 2) = make_float2(pm, pq);
+    float amax = 0.f;
 #pragma unroll
     for (int kk = 0; kk < CPT; ++kk) {
         typename T::vec4 o;
+        f16x4 lo;
+        f32x4 back;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = T::from_f32(v[kk][j]);
-        *(typename T::vec4*)(x16 + lds_image_index(row, k * BN + (l16 + 16 * kk) * 4, C)) = o;
+        for (int j = 0; j < 4; ++j) {
+            o[j] = T::from_f32(v[kk][j]);
+            lo[j] = FP16::from_f32(v[kk][j] - T::to_f32(o[j]));
+            back[j] = T::to_f32(o[j]) + (float)lo[j];
+            amax = fmaxf(amax, fabsf(v[kk][j]));
+        }
+        const int64_t e = lds_image_index(row, k * BN + (l16 + 16 * kk) * 4, C);
+        *(typename T::vec4*)(x16 + e) = o;
+        if (lo16) *(f16x4*)(lo16 + e) = lo;
+        if (x_rw) *(f32x4*)(x_rw + row * C + k * BN + (l16 + 16 * kk) * 4) = back;
+    }
+    if constexpr (std::is_same<T, FP16>::value) {
+        if (amax >= 65504.f && overflow) *(volatile int*)overflow = 1;
+    }
+}
+
+// Split stream -> fp32 rows: out[row][col] = float(hi) + float(lo), planes in LDS-image order (taps, the neck's input in bf16 mode,
+// operand-type boundaries between blocks).  One thread per 16-byte chunk of a plane (8 elements).
+template <class T>
+__global__ __launch_bounds__(256) void stream_merge_kernel(const u16* __restrict__ hi, const u16* __restrict__ lo, float* __restrict__ out,
+                                                           int64_t rows, int C) {
+    const int64_t n16 = rows * (C / 8);
+    const int kts = C >> 5;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+        // chunk i of the image: [row block][K-step][position], position = (row % 16) * 4 + swizzled chunk
+        const int pos = (int)(i & 63);
+        const int64_t piece = i >> 6;
+        const int kt = (int)(piece % kts);
+        const int64_t rb = piece / kts;
+        const int r = pos >> 2, chunk = (pos & 3) ^ ((0 - (r >> 2)) & 3);
+        const typename T::vec8 h = *(const typename T::vec8*)(hi + i * 8);
+        const f16x8 l = *(const f16x8*)(lo + i * 8);
+        float* dst = out + (rb * 16 + r) * C + kt * 32 + chunk * 8;
+        f32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = T::to_f32(h[j]) + (float)l[j];
+            b[j] = T::to_f32(h[4 + j]) + (float)l[4 + j];
+        }
+        *(f32x4*)dst = a;
+        *(f32x4*)(dst + 4) = b;
+    }
+}
+
+// LDS-image order -> row-major (the neck's first GEMM where it is a half-width launch: 1-4 tiles per call)
+__global__ __launch_bounds__(256) void unpack16_lds_image_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t rows, int K) {
+    const int64_t n16 = rows * (K / 8);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / (K / 8);
+        const int col = (int)(i - row * (K / 8)) * 8;
+        out[i] = in[lds_image_index(row, col, K) >> 3];
     }
 }
 

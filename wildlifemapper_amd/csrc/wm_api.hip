@@ -239,7 +239,15 @@ struct wm_handle {
     // statistics of the residual stream [maxB * 4096][<= 4][2]
     std::map<std::string, uint16_t*> wfold;
     std::map<std::string, float*> fold_c1, fold_c2;
+    std::map<std::string, float*> wsrc32;   // fp32 device copies of the weights that get folded (qkv, lin1 of every block): gamma (.) W is rounded once
     float* fold_stats = nullptr;
+    // split stream (gemm16_v5.h "Split stream"): xn16 = hi plane, lo16 = lo plane, both LDS-image order; `split`: used wherever the
+    // residual GEMMs of a folded block run the 256-row-tile kernel (WM_STREAM_SPLIT=0 keeps the fp32 stream: A/B runs).
+    // overflow: host-pinned, device-visible word the stream's producers set when an fp16 hi plane clamps (wm_stream_overflow).
+    uint16_t* lo16 = nullptr;
+    bool split = false;
+    bool fold_from16 = false;               // WM_FOLD_FROM16=1 (A/B runs): gamma (.) W from the 16-bit weight, rounded twice (round 3's form)
+    int* overflow = nullptr;
     bool fold = false, fold_bf16 = false;   // WM_CFG_FOLD_LN: fp16-operand blocks; WM_CFG_FOLD_LN_BF16: bf16-operand blocks too
     std::map<std::string, uint16_t*> w16p;  // the same weights in LDS-image order (gemm16_v5.h "Operand layout"), for the 256-row-tile kernels
     std::map<std::string, uint8_t*> w8;     // WM_PREC_FP8: e4m3 weights of the blocks' GEMMs; their per-channel scales live in w32[name + ".wscale"]
@@ -328,7 +336,8 @@ int launch_gemm16_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     count_variant(WM_GEMM_V1_128);
     const int grid = (a.M / G16_BM) * (a.N / G16_BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
-               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
+               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N +
+                   (a.residual ? 4.0 * (double)(a.res_mod > 0 ? a.res_mod : a.M) * a.N : 0.0));
     hipLaunchKernelGGL(gemm16_kernel<T16>, dim3(grid), dim3(256), G16_LDS_BYTES, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -340,7 +349,8 @@ int launch_gemm16v2_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     count_variant(BN == 160 ? WM_GEMM_V2_160 : WM_GEMM_V2_128);
     const int grid = (a.M / 256) * (a.N / BN);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
-               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
+               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N +
+                   (a.residual ? 4.0 * (double)(a.res_mod > 0 ? a.res_mod : a.M) * a.N : 0.0));
     hipLaunchKernelGGL((gemm16v2_kernel<T16, BN>), dim3(grid), dim3(512), G2<BN>::LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -359,7 +369,8 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
     if (const char* e = getenv("WM_GEMM_GROUP_M")) { if (atoi(e) > 0) a.group_m = atoi(e); }     // dev build only: tile-order A/B
 #endif
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
-               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N);
+               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N +
+                   (a.residual ? 4.0 * (double)(a.res_mod > 0 ? a.res_mod : a.M) * a.N : 0.0));
 #if WM_DEV_TIMELINE
     if constexpr (BN == 320 && NSLOT == 3) {
         static const bool dbg = getenv("WM_GEMM_DBG") != nullptr;          // dev: in-kernel interval timing of workgroup 0
@@ -449,6 +460,9 @@ static bool gemm16_takes_v5(int M, int N, int K) {
 //   st_stats: folded-LayerNorm PRODUCER (fp32 + residual form): per-row partial statistics out, out16 = 16-bit copy of the
 //             rows in LDS-image order;
 //   fold_stats / fold_c1 / fold_eps: folded-LayerNorm CONSUMER (16-bit-only form): A = such a copy, W = gamma (.) W, bias = c2.
+//   res_hi / res_lo / out_lo: split stream (gemm16_v5.h "Split stream"): with st_stats, the residual as two 16-bit planes in
+//             (res_hi, res_lo; no fp32 residual) and out (out16 = hi, out_lo); out_lo alone: the fp32-residual producer also
+//             writes the lo plane (and no fp32 output when out32 is null).
 struct GemmExtra {
     const void* Wp = nullptr;
     int a_packed = 0, out_packed = 0;
@@ -456,6 +470,10 @@ struct GemmExtra {
     const float* fold_stats = nullptr;
     const float* fold_c1 = nullptr;
     float fold_eps = 0.f;
+    const void* res_hi = nullptr;
+    const void* res_lo = nullptr;
+    void* out_lo = nullptr;
+    int* overflow = nullptr;
 };
 static GemmExtra GX(const void* Wp, int a_packed = 0, int out_packed = 0) {
     GemmExtra x;
@@ -465,16 +483,18 @@ static GemmExtra GX(const void* Wp, int a_packed = 0, int out_packed = 0) {
 // column-tile width of the folded LayerNorm's partial statistics over C channels (the producer GEMM's tile width at N = C)
 static int fold_bn_for(int C) { return C % 320 == 0 ? 320 : 256; }
 
-template <class T16, int BN>
+template <class T16, int BN, bool SPLIT = false>
 int launch_gemm16v5_foldp_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     using G = G3<BN, 4>;
     constexpr int LDS = 3 * G::STAGE + 32 * BN * 4;
-    WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, true>, LDS));
-    count_variant(BN == 320 ? WM_GEMM_V5_320_FOLDP : WM_GEMM_V5_256_FOLDP);
+    WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, true, false, SPLIT>, LDS));
+    count_variant(SPLIT ? (BN == 320 ? WM_GEMM_V5_320_SPLIT : WM_GEMM_V5_256_SPLIT) : (BN == 320 ? WM_GEMM_V5_320_FOLDP : WM_GEMM_V5_256_FOLDP));
     const int grid = (a.M / 256) * (a.N / BN);
+    // algorithmic bytes: operands + the stream in and out (split: 2 + 2 B in, 2 + 2 B out; fp32: 4 in, 4 + 2 out, or 2 + 2 out with a lo plane)
+    const double stream_bytes = SPLIT ? 8.0 : 4.0 + (a.out32 ? 4.0 : 0.0) + 2.0 + (a.out_lo ? 2.0 : 0.0);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
-               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + 10.0 * a.M * a.N);
-    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, true>), dim3(grid), dim3(512), LDS, s, a);
+               2.0 * ((double)a.M * a.K + (double)a.N * a.K) + stream_bytes * a.M * a.N);
+    hipLaunchKernelGGL((gemm16v5_kernel<T16, BN, 3, false, true, false, SPLIT>), dim3(grid), dim3(512), LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -500,16 +520,26 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
     if (M <= 0 || N <= 0 || K <= 0 || M % G16_BM || N % G16_BN || K % G16_BK)
         return fail("gemm16: shape M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, G16_BM, G16_BN, G16_BK);
     if (!out32 && !out16) return fail("gemm16: no output");
-    Gemm16Args a{(const u16*)A, (const u16*)W, bias, res, out32, (u16*)out16, M, N, K, res_mod, act, 0, nullptr};
+    Gemm16Args a{};
+    a.A = (const u16*)A; a.W = (const u16*)W; a.bias = bias; a.residual = res; a.out32 = out32; a.out16 = (u16*)out16;
+    a.M = M; a.N = N; a.K = K; a.res_mod = res_mod; a.act = act;
     if (gemm16_takes_v5(M, N, K)) {         // staggered wave groups (gemm16_v5.h)
         if (Wp) { a.W = (const u16*)Wp; a.w_packed = 1; }
         a.a_packed = a_packed;
         a.out_packed = out_packed;
         if (out_packed && (out32 || res || !out16)) return fail("gemm16: a packed output is the 16-bit-only form (no fp32 output, no residual)");
         if (x.st_stats) {                   // folded LayerNorm, producer
-            if (!res || !out32 || !out16 || act != ACT_NONE || N / (N % 320 == 0 ? 320 : 256) > 4)
-                return fail("gemm16: the statistics-producing form is fp32 + residual with a 16-bit copy, no activation, at most 4 column tiles");
+            const bool split = x.res_hi != nullptr;
+            if (!out16 || act != ACT_NONE || N / (N % 320 == 0 ? 320 : 256) > 4 || N % 32)
+                return fail("gemm16: the statistics-producing form has a 16-bit copy, no activation, at most 4 column tiles");
+            if (split ? (res || out32 || !x.res_lo || !x.out_lo || res_mod) : (!res || (!out32 && !x.out_lo)))
+                return fail("gemm16: the statistics-producing form takes an fp32 residual (fp32 and / or lo-plane output) or the two planes of a split stream (planes out)");
             a.st_stats = x.st_stats;
+            a.res_hi = (const u16*)x.res_hi; a.res_lo = (const u16*)x.res_lo; a.out_lo = (u16*)x.out_lo; a.overflow = x.overflow;
+            if (split) {
+                if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_foldp_t<BF16, 320, true>(h, s, a)), (launch_gemm16v5_foldp_t<FP16, 320, true>(h, s, a)));
+                return WM_BY_PREC((launch_gemm16v5_foldp_t<BF16, 256, true>(h, s, a)), (launch_gemm16v5_foldp_t<FP16, 256, true>(h, s, a)));
+            }
             if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_foldp_t<BF16, 320>(h, s, a)), (launch_gemm16v5_foldp_t<FP16, 320>(h, s, a)));
             return WM_BY_PREC((launch_gemm16v5_foldp_t<BF16, 256>(h, s, a)), (launch_gemm16v5_foldp_t<FP16, 256>(h, s, a)));
         }
@@ -524,7 +554,7 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
         if (N % 320 == 0) return WM_BY_PREC((launch_gemm16v5_t<BF16, 320>(h, s, a)), (launch_gemm16v5_t<FP16, 320>(h, s, a)));
         return WM_BY_PREC((launch_gemm16v5_t<BF16, 256>(h, s, a)), (launch_gemm16v5_t<FP16, 256>(h, s, a)));
     }
-    if (a_packed || out_packed || x.st_stats || x.fold_stats)
+    if (a_packed || out_packed || x.st_stats || x.fold_stats || x.res_hi || x.out_lo)
         return fail("gemm16: M=%d N=%d K=%d runs on a half-width kernel, which takes row-major operands only", M, N, K);
     if (M % 256 == 0) {
         // half-width tiles: 256 x 160 where N allows and it fills the last round at least as well as 256 x 128
@@ -607,7 +637,8 @@ int launch_conv3x3_16(wm_handle* h, hipStream_t s, int prec, const void* A, cons
     if (M % 4096 || N % 256 || Cin % 32) return fail("conv3x3: M=%d N=%d C=%d unsupported (M %% 4096, N %% 256, C %% 32)", M, N, Cin);
     const uint16_t* zero_page = nullptr;       // 256 B of zeros for out-of-image taps (one per device)
     WM_TRY(zero_page_for_device(&zero_page));
-    Gemm16Args a{(const u16*)A, (const u16*)W, nullptr, nullptr, out32, nullptr, M, N, 9 * Cin, 0, ACT_NONE, Cin, (const u16*)zero_page};
+    Gemm16Args a{};
+    a.A = (const u16*)A; a.W = (const u16*)W; a.out32 = out32; a.M = M; a.N = N; a.K = 9 * Cin; a.act = ACT_NONE; a.conv_c = Cin; a.zero_page = (const u16*)zero_page;
     using G = G3<256, 4>;
     WM_TRY(set_max_lds((const void*)gemm16v3_kernel<FP16, 256, 4, 1>, G::LDS));
     WM_TRY(set_max_lds((const void*)gemm16v3_kernel<BF16, 256, 4, 1>, G::LDS));
@@ -1076,6 +1107,8 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     h->row_major = getenv("WM_ROW_MAJOR_OPERANDS") && atoi(getenv("WM_ROW_MAJOR_OPERANDS")) != 0;
     h->fold = (cfg->flags & (WM_CFG_FOLD_LN | WM_CFG_FOLD_LN_BF16)) != 0 && !h->row_major;
     h->fold_bf16 = (cfg->flags & WM_CFG_FOLD_LN_BF16) != 0;
+    h->fold_from16 = getenv("WM_FOLD_FROM16") && atoi(getenv("WM_FOLD_FROM16")) != 0;
+    h->split = h->fold && !(getenv("WM_STREAM_SPLIT") && atoi(getenv("WM_STREAM_SPLIT")) == 0);
     h->fp8_gemms = cfg->fp8_gemms ? (cfg->fp8_gemms & WM_FP8_ALL) : (getenv("WM_FP8_GEMMS") ? (atoi(getenv("WM_FP8_GEMMS")) & WM_FP8_ALL) : WM_FP8_ALL);
     if (cfg->precision == WM_PREC_FP8 && h->fp8_gemms == 0) { delete h; return fail("wm_create: fp8_gemms selects no GEMM"); }
     h->D = cfg->embed_dim; h->depth = cfg->depth; h->heads = cfg->num_heads; h->hd = hd;
@@ -1109,7 +1142,13 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     A(records, B * NQ * sizeof(wm_box_record));
     A(sat_counts, WM_SAT_COUNT * sizeof(unsigned long long));
     A(fold_stats, BT * 4 * 2 * 4);
+    A(lo16, BT * D * 2);
 #undef A
+    if (!r) {
+        void* pf = nullptr;
+        if (hipHostMalloc(&pf, 64, hipHostMallocMapped) != hipSuccess) r = fail("wm_create: hipHostMalloc failed");
+        else { h->overflow = (int*)pf; *h->overflow = 0; }
+    }
     if (r) { wm_destroy(h); return r; }
     // FFT twiddles exp(-2 pi i k / 1024), computed in double
     {
@@ -1134,6 +1173,7 @@ extern "C" int wm_destroy(wm_handle* h) {
     hipDeviceSynchronize();
     for (void* p : h->allocs) if (p) hipFree(p);
     if (h->tap_buf) hipFree(h->tap_buf);
+    if (h->overflow) hipHostFree(h->overflow);
     for (auto& e : h->prof.used) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : h->prof.pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete h;
@@ -1188,6 +1228,8 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
         if (i16p != h->w16p.end()) { hipFree(i16p->second); for (auto& a : h->allocs) if (a == i16p->second) a = nullptr; h->w16p.erase(i16p); }
         auto i32 = h->w32.find(kv.first);
         if (i32 != h->w32.end()) { hipFree(i32->second); for (auto& a : h->allocs) if (a == i32->second) a = nullptr; h->w32.erase(i32); }
+        auto is32 = h->wsrc32.find(kv.first);
+        if (is32 != h->wsrc32.end()) { hipFree(is32->second); for (auto& a : h->allocs) if (a == is32->second) a = nullptr; h->wsrc32.erase(is32); }
         auto i8 = h->w8.find(kv.first);
         if (i8 != h->w8.end()) { hipFree(i8->second); for (auto& a : h->allocs) if (a == i8->second) a = nullptr; h->w8.erase(i8); }
         auto isc = h->w32.find(kv.first + ".wscale");
@@ -1231,6 +1273,13 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
                 HIP_TRY(hipGetLastError());
                 h->w16p[name] = dp;
             }
+            // a weight the folded LayerNorm multiplies by gamma: keep the fp32 values on the device (1.47 GB for ViT-H, of 288)
+            if (h->fold && name.rfind("image_encoder.blocks.", 0) == 0 && (ends_with(name, "attn.qkv.weight") || ends_with(name, "mlp.lin1.weight"))) {
+                float* d32 = nullptr;
+                WM_TRY(dalloc(h, &d32, n * 4));
+                HIP_TRY(hipMemcpy(d32, w.data.data(), n * 4, hipMemcpyHostToDevice));
+                h->wsrc32[name] = d32;
+            }
         } else {
             WM_TRY(upload32(h, name, w.data.data(), n));
         }
@@ -1253,7 +1302,7 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
         HIP_TRY(hipMemcpy(h->kpe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
     }
     // Folded LayerNorm: gamma (.) W (LDS-image order), c1, c2 of every block's qkv (norm1) and lin1 (norm2), from the DEVICE
-    // copies (the 16-bit row-major weight as packed above), so a later partial re-upload folds to the same bits as a full one.
+    // copies of the fp32 weights (kept above), so a later partial re-upload folds to the same bits as a full one.
     if (h->fold && h->enc_ready) {
         for (int i = 0; i < h->depth; ++i) {
             const std::string b = "image_encoder.blocks." + std::to_string(i) + ".";
@@ -1272,9 +1321,9 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
                 const float* be = h->w32.at(b + pr.second + ".bias");
                 const float* bias = h->w32.at(b + pr.first + ".bias");
                 if (P == WM_PREC_FP16)
-                    hipLaunchKernelGGL(fold_weight_kernel<FP16>, dim3(N), dim3(256), 0, 0, (const u16*)h->w16.at(wn), g, be, bias, (u16*)h->wfold[wn], h->fold_c1[wn], h->fold_c2[wn], N, K);
+                    hipLaunchKernelGGL(fold_weight_kernel<FP16>, dim3(N), dim3(256), 0, 0, (const u16*)h->w16.at(wn), h->fold_from16 ? (const float*)nullptr : (const float*)h->wsrc32.at(wn), g, be, bias, (u16*)h->wfold[wn], h->fold_c1[wn], h->fold_c2[wn], N, K);
                 else
-                    hipLaunchKernelGGL(fold_weight_kernel<BF16>, dim3(N), dim3(256), 0, 0, (const u16*)h->w16.at(wn), g, be, bias, (u16*)h->wfold[wn], h->fold_c1[wn], h->fold_c2[wn], N, K);
+                    hipLaunchKernelGGL(fold_weight_kernel<BF16>, dim3(N), dim3(256), 0, 0, (const u16*)h->w16.at(wn), h->fold_from16 ? (const float*)nullptr : (const float*)h->wsrc32.at(wn), g, be, bias, (u16*)h->wfold[wn], h->fold_c1[wn], h->fold_c2[wn], N, K);
                 HIP_TRY(hipGetLastError());
             }
         }
@@ -1319,6 +1368,14 @@ int do_tap(wm_handle* h, hipStream_t s, int which, int batch, const float* src =
     HIP_TRY(hipMemcpyAsync(h->tap_buf, src ? src : h->resid, (size_t)batch * T * h->D * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
+int tap_alloc(wm_handle* h) {
+    if (!h->tap_buf) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, (size_t)h->maxB * T * h->D * 4));
+        h->tap_buf = (float*)p;
+    }
+    return 0;
+}
 
 int fft_impl(wm_handle* h, const float* x, float* out, int B, hipStream_t s) {
     WM_TRY(launch_simple(h, s, (double)B * (12e6 + 3e6), fft_rows_fwd_kernel, dim3(FFT_N, B), dim3(256), x, h->fftR, (const float2*)h->fft_tw));
@@ -1329,19 +1386,31 @@ int fft_impl(wm_handle* h, const float* x, float* out, int B, hipStream_t s) {
 }
 
 // Folded LayerNorm, standalone producer (ln_stats_x16_kernel): partial statistics + 16-bit copy of `rows` fp32 rows of C channels
-int launch_ln_stats16(wm_handle* h, hipStream_t s, int prec, const float* x, float* stats, void* x16, int64_t rows, int C) {
+int launch_ln_stats16(wm_handle* h, hipStream_t s, int prec, const float* x, float* stats, void* x16, int64_t rows, int C,
+                      void* lo16 = nullptr, float* x_rw = nullptr, int* overflow = nullptr) {
     const int bn = fold_bn_for(C);
     if (C % bn || C / bn > 4 || rows % 16 || C % 32 || (prec != WM_PREC_FP16 && prec != WM_PREC_BF16))
         return fail("ln_stats16: rows=%lld C=%d precision %d unsupported", (long long)rows, C, prec);
     const dim3 grid((unsigned)((rows + 3) / 4));
-    Bracket br(h, s, WM_KCLASS_LAYERNORM, 0.0, (double)rows * C * 6.0);
+    Bracket br(h, s, WM_KCLASS_LAYERNORM, 0.0, (double)rows * C * (6.0 + (lo16 ? 2.0 : 0.0) + (x_rw ? 4.0 : 0.0)));
     if (bn == 320) {
-        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((ln_stats_x16_kernel<FP16, 320>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C);
-        else hipLaunchKernelGGL((ln_stats_x16_kernel<BF16, 320>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C);
+        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((ln_stats_x16_kernel<FP16, 320>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C, (u16*)lo16, x_rw, overflow);
+        else hipLaunchKernelGGL((ln_stats_x16_kernel<BF16, 320>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C, (u16*)lo16, x_rw, overflow);
     } else {
-        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((ln_stats_x16_kernel<FP16, 256>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C);
-        else hipLaunchKernelGGL((ln_stats_x16_kernel<BF16, 256>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C);
+        if (prec == WM_PREC_FP16) hipLaunchKernelGGL((ln_stats_x16_kernel<FP16, 256>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C, (u16*)lo16, x_rw, overflow);
+        else hipLaunchKernelGGL((ln_stats_x16_kernel<BF16, 256>), grid, dim3(256), 0, s, x, stats, (u16*)x16, rows, C, (u16*)lo16, x_rw, overflow);
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// split stream -> fp32 rows (stream_merge_kernel): out[row][col] = float(hi) + float(lo)
+int launch_stream_merge(wm_handle* h, hipStream_t s, int prec, const void* hi, const void* lo, float* out, int64_t rows, int C) {
+    if (rows % 16 || C % 32 || (prec != WM_PREC_FP16 && prec != WM_PREC_BF16)) return fail("stream_merge: rows=%lld C=%d precision %d", (long long)rows, C, prec);
+    Bracket br(h, s, WM_KCLASS_OTHER, 0.0, (double)rows * C * 8.0);
+    const dim3 grid(grid_for(rows * (C / 8)));
+    if (prec == WM_PREC_FP16) hipLaunchKernelGGL(stream_merge_kernel<FP16>, grid, dim3(256), 0, s, (const u16*)hi, (const u16*)lo, out, rows, C);
+    else hipLaunchKernelGGL(stream_merge_kernel<BF16>, grid, dim3(256), 0, s, (const u16*)hi, (const u16*)lo, out, rows, C);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1405,16 +1474,60 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
         return h->fold && (pb == WM_PREC_FP16 || (pb == WM_PREC_BF16 && h->fold_bf16)) && gemm16_takes_v5(M, 3 * D, D) && gemm16_takes_v5(M, 4 * D, D) &&
                h->wfold.count(b + "attn.qkv.weight") && h->wfold.count(b + "mlp.lin1.weight");
     };
+    // Where the residual stream lives.  st_split: as the two 16-bit planes (xn16 = hi of type raw_prec, lo16), fp32 `resid` stale;
+    // otherwise in `resid` (fp32), with xn16 / fold_stats its hi plane and statistics iff raw_prec >= 0.  The split form is used by
+    // a call whose residual GEMMs run the 256-row-tile kernel (4+ tiles for ViT-H); a smaller call keeps fp32 and rounds the stream
+    // to hi + lo in ln_stats_x16_kernel, so both forms carry the same values bit for bit (gemm16_v5.h "Split stream").
+    const bool split_call = h->split && gemm16_takes_v5(M, D, D) && gemm16_takes_v5(M, D, 4 * D);
+    bool st_split = false;
     int raw_prec = -1;
+    auto to_fp32 = [&]() -> int {                           // planes -> resid (type boundaries, non-folded blocks, the bf16 neck input)
+        if (st_split) WM_TRY(launch_stream_merge(h, s, raw_prec, h->xn16, h->lo16, h->resid, M, D));
+        st_split = false;
+        return 0;
+    };
+    auto planes_from_fp32 = [&](int P) -> int {             // resid -> statistics + planes of type P (resid rounded in place unless the call is split)
+        WM_TRY(to_fp32());
+        WM_TRY(launch_ln_stats16(h, s, P, h->resid, h->fold_stats, h->xn16, M, D, h->lo16, split_call ? nullptr : h->resid, h->overflow));
+        raw_prec = P;
+        st_split = split_call;
+        return 0;
+    };
+    auto tap = [&](int which) -> int {
+        if (h->tap_which != which) return 0;
+        if (!st_split) return do_tap(h, s, which, B);
+        WM_TRY(tap_alloc(h));
+        return launch_stream_merge(h, s, raw_prec, h->xn16, h->lo16, h->tap_buf, M, D);
+    };
+    // a residual GEMM of a folded block of type P: x += A W^T + b, leaving the stream with planes + statistics of type P
+    auto residual_gemm = [&](int P, const void* A, const std::string& wn, int K, int a_packed) -> int {
+        GemmExtra x = GX(W16P(h, wn + ".weight"), a_packed);
+        if (st_split) {                                     // planes in, planes out (in place), statistics out
+            x.st_stats = h->fold_stats; x.res_hi = h->xn16; x.res_lo = h->lo16; x.out_lo = h->lo16; x.overflow = h->overflow;
+            return launch_gemm16(h, s, P, A, W16(h, wn + ".weight"), W32(h, wn + ".bias"), nullptr, 0, nullptr, h->xn16, M, D, K, ACT_NONE, x);
+        }
+        const bool v5 = gemm16_takes_v5(M, D, K);
+        if (v5 && !h->split) {                              // fp32 stream (WM_STREAM_SPLIT=0): statistics + 16-bit copy from the GEMM, as in round 3
+            x.st_stats = h->fold_stats;
+            WM_TRY(launch_gemm16(h, s, P, A, W16(h, wn + ".weight"), W32(h, wn + ".bias"), h->resid, 0, h->resid, h->xn16, M, D, K, ACT_NONE, x));
+            raw_prec = P;
+            return 0;
+        }
+        // half-width launch (1-2 tiles per call), or a call whose proj and lin2 disagree about the kernel: fp32 in place, then the
+        // standalone statistics kernel, which also rounds the stream to hi + lo
+        WM_TRY(launch_gemm16(h, s, P, A, W16(h, wn + ".weight"), W32(h, wn + ".bias"), h->resid, 0, h->resid, nullptr, M, D, K, ACT_NONE, x));
+        raw_prec = -1;
+        return planes_from_fp32(P);
+    };
     {
         GemmExtra xb = GX(W16P(h, a + "proj_back.weight"));
-        const bool produce = fold_block(0) && block_prec(h, 0) == PS && gemm16_takes_v5(M, D, HFC);
-        if (produce) xb.st_stats = h->fold_stats;
+        const bool produce = fold_block(0) && block_prec(h, 0) == PS && gemm16_takes_v5(M, D, HFC) && (split_call || !h->split);
+        if (produce) { xb.st_stats = h->fold_stats; xb.overflow = h->overflow; if (split_call) xb.out_lo = h->lo16; }
         WM_TRY(launch_gemm16(h, s, PS, h->y2t16, W16(h, a + "proj_back.weight"), W32(h, a + "proj_back.bias"), h->tokbase, 0,
-                             h->resid, produce ? h->xn16 : nullptr, M, D, HFC, ACT_NONE, xb));
-        if (produce) raw_prec = PS;
+                             (produce && split_call) ? nullptr : h->resid, produce ? h->xn16 : nullptr, M, D, HFC, ACT_NONE, xb));
+        if (produce) { raw_prec = PS; st_split = split_call; }
     }
-    WM_TRY(do_tap(h, s, -1, B));
+    WM_TRY(tap(-1));
 
     // ---- transformer blocks (image_encoder.py:188-204) ----
     // x = x + proj(attn(norm1 x)); x = x + lin2(gelu(lin1(norm2 x))).
@@ -1436,43 +1549,30 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
         const bool pk_qkv = !h->row_major && !q8 && gemm16_takes_v5(M, 3 * D, D), pk_lin1 = !h->row_major && !m8 && gemm16_takes_v5(M, 4 * D, D);
         const bool pk_lin2 = pk_lin1 && gemm16_takes_v5(M, D, 4 * D);
         if (fold_block(i)) {
-            // ---- both LayerNorms folded: statistics from the producing residual GEMM (or the standalone kernel where that one is
-            // a half-width launch or of another operand type), normalisation in the consuming GEMM's epilogue ----
+            // ---- both LayerNorms folded: statistics (and the stream's hi plane = the operand) from the producing residual GEMM, or
+            // from the standalone kernel where that one is a half-width launch or of another operand type; normalisation in the
+            // consuming GEMM's epilogue ----
             auto folded = [&](const std::string& wn, int act, int out_packed, void* out, int N) {
                 GemmExtra x = GX(h->wfold.at(wn), 1, out_packed);
                 x.fold_stats = h->fold_stats; x.fold_c1 = h->fold_c1.at(wn); x.fold_eps = 1e-6f;
                 return launch_gemm16(h, s, P, h->xn16, W16(h, wn), h->fold_c2.at(wn), nullptr, 0, nullptr, out, M, N, D, act, x);
             };
-            if (raw_prec != P) WM_TRY(launch_ln_stats16(h, s, P, h->resid, h->fold_stats, h->xn16, M, D));
+            if (raw_prec != P) WM_TRY(planes_from_fp32(P));
             WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, P));
             WM_TRY(folded(b + "attn.qkv.weight", ACT_NONE, 0, h->qkv16, 3 * D));
             WM_TRY(sat_check(h, s, WM_SAT_QKV, h->qkv16, (int64_t)M * 3 * D, P));
             WM_TRY(launch_encoder_attention(h, s, P, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
                                             W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14, nullptr));
             WM_TRY(sat_check(h, s, WM_SAT_ATTN, h->ao16, (int64_t)M * D, P));
-            {
-                GemmExtra x = GX(W16P(h, b + "attn.proj.weight"));
-                const bool produce = gemm16_takes_v5(M, D, D);
-                if (produce) x.st_stats = h->fold_stats;
-                WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
-                                     h->resid, produce ? h->xn16 : nullptr, M, D, D, ACT_NONE, x));
-                raw_prec = produce ? P : -1;
-            }
-            if (raw_prec != P) WM_TRY(launch_ln_stats16(h, s, P, h->resid, h->fold_stats, h->xn16, M, D));
+            WM_TRY(residual_gemm(P, h->ao16, b + "attn.proj", D, 0));
             WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, P));
             WM_TRY(folded(b + "mlp.lin1.weight", ACT_GELU, pk_lin2, h->hid16, 4 * D));
             WM_TRY(sat_check(h, s, WM_SAT_HID, h->hid16, (int64_t)M * 4 * D, P));
-            {
-                GemmExtra x = GX(W16P(h, b + "mlp.lin2.weight"), pk_lin2);
-                const bool produce = i + 1 < h->depth && fold_block(i + 1) && block_prec(h, i + 1) == P && gemm16_takes_v5(M, D, 4 * D);
-                if (produce) x.st_stats = h->fold_stats;
-                WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
-                                     h->resid, produce ? h->xn16 : nullptr, M, D, 4 * D, ACT_NONE, x));
-                raw_prec = produce ? P : -1;
-            }
-            WM_TRY(do_tap(h, s, i, B));
+            WM_TRY(residual_gemm(P, h->hid16, b + "mlp.lin2", 4 * D, pk_lin2));
+            WM_TRY(tap(i));
             continue;
         }
+        WM_TRY(to_fp32());
         raw_prec = -1;
         WM_TRY(launch_layernorm_block(h, s, q8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D, pk_qkv));
         xn_packed = pk_qkv;
@@ -1516,9 +1616,19 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     }
 
     // ---- neck (image_encoder.py:105-121,136) ----
-    WM_TRY(launch_simple(h, s, B * 31.5e6, cvt_f32_to_16_kernel<FP16>, dim3(grid_for((int64_t)M * D / 4)), dim3(256), (const float*)h->resid, (u16*)h->x16last, (int64_t)M * D / 4));
-    WM_TRY(sat_check(h, s, WM_SAT_LAST, h->x16last, (int64_t)M * D, PS));
-    WM_TRY(launch_gemm16(h, s, PS, h->x16last, W16(h, e + "neck.0.weight"), nullptr, nullptr, 0, h->n1, nullptr, M, OUTC, D, ACT_NONE, GX(W16P(h, e + "neck.0.weight"))));
+    // the neck's operand is fp16(x).  With the split stream and fp16 blocks that is the hi plane itself (LDS-image order: the
+    // 256-row-tile kernel takes it as it is, a half-width launch gets it unpacked); otherwise fp16 of the fp32 stream.
+    const void* neck_a = h->x16last;
+    int neck_packed = 0;
+    if (h->split && raw_prec == PS) {
+        if (gemm16_takes_v5(M, OUTC, D)) { neck_a = h->xn16; neck_packed = 1; }
+        else WM_TRY(launch_simple(h, s, B * 21.0e6, unpack16_lds_image_kernel, dim3(grid_for((int64_t)M * D / 8)), dim3(256), (const uint4*)h->xn16, (uint4*)h->x16last, (int64_t)M, D));
+    } else {
+        WM_TRY(to_fp32());
+        WM_TRY(launch_simple(h, s, B * 31.5e6, cvt_f32_to_16_kernel<FP16>, dim3(grid_for((int64_t)M * D / 4)), dim3(256), (const float*)h->resid, (u16*)h->x16last, (int64_t)M * D / 4));
+    }
+    WM_TRY(sat_check(h, s, WM_SAT_LAST, neck_a, (int64_t)M * D, PS));
+    WM_TRY(launch_gemm16(h, s, PS, neck_a, W16(h, e + "neck.0.weight"), nullptr, nullptr, 0, h->n1, nullptr, M, OUTC, D, ACT_NONE, GX(W16P(h, e + "neck.0.weight"), neck_packed)));
     WM_TRY(launch_layernorm(h, s, PS, h->n1, W32(h, e + "neck.1.weight"), W32(h, e + "neck.1.bias"), 1e-6f, nullptr, h->n1n16, M, OUTC));
     WM_TRY(launch_conv3x3_16(h, s, PS, h->n1n16, W16(h, e + "neck.2.weight"), h->n2, M, OUTC, OUTC));
     WM_TRY(launch_layernorm(h, s, PS, h->n2, W32(h, e + "neck.3.weight"), W32(h, e + "neck.3.bias"), 1e-6f, h->emb_nhwc, nullptr, M, OUTC));
@@ -1724,6 +1834,13 @@ extern "C" int wm_profile_read(wm_handle* h, wm_kclass_stat* out) {
     WM_TRY(prof_collect(h));
     for (int i = 0; i < WM_KCLASS_COUNT; ++i) out[i] = h->prof.acc[i];
     return 0;
+}
+
+extern "C" int wm_stream_overflow(wm_handle* h, int reset) {
+    if (!h || !h->overflow) return fail("wm_stream_overflow: null handle");
+    const int v = *(volatile int*)h->overflow;
+    if (reset) *(volatile int*)h->overflow = 0;
+    return v != 0 ? 1 : 0;
 }
 
 extern "C" int wm_debug_saturation_enable(wm_handle* h, int on) {
@@ -1944,14 +2061,42 @@ extern "C" int wm_op_ln_stats16(const float* x_dev, float* stats_dev, void* x16_
     return launch_ln_stats16(nullptr, (hipStream_t)stream, precision, x_dev, stats_dev, x16_dev, rows, C);
 }
 
+extern "C" int wm_op_ln_stats16_split(const float* x_dev, float* stats_dev, void* hi_dev, void* lo_dev, float* x_rw_dev, int64_t rows, int C,
+                                      int precision, void* stream) {
+    if (!x_dev || !stats_dev || !hi_dev || !lo_dev) return fail("wm_op_ln_stats16_split: null buffer");
+    return launch_ln_stats16(nullptr, (hipStream_t)stream, precision, x_dev, stats_dev, hi_dev, rows, C, lo_dev, x_rw_dev, nullptr);
+}
+
+extern "C" int wm_op_stream_merge(const void* hi_dev, const void* lo_dev, float* out_dev, int64_t rows, int C, int precision, void* stream) {
+    if (!hi_dev || !lo_dev || !out_dev) return fail("wm_op_stream_merge: null buffer");
+    return launch_stream_merge(nullptr, (hipStream_t)stream, precision, hi_dev, lo_dev, out_dev, rows, C);
+}
+
+extern "C" int wm_op_gemm16_split(const void* a_dev, const void* w_dev, const float* bias_dev, void* hi_dev, void* lo_dev, float* stats_dev,
+                                  int M, int N, int K, int layout, int precision, void* stream) {
+    if (!a_dev || !w_dev || !hi_dev || !lo_dev || !stats_dev) return fail("wm_op_gemm16_split: null buffer");
+    if (!gemm16_takes_v5(M, N, K)) return fail("wm_op_gemm16_split: M=%d N=%d K=%d is not served by the 256-row-tile kernel", M, N, K);
+    GemmExtra x = GX((layout & WM_GEMM_W_PACKED) ? w_dev : nullptr, (layout & WM_GEMM_A_PACKED) != 0, 0);
+    x.st_stats = stats_dev; x.res_hi = hi_dev; x.res_lo = lo_dev; x.out_lo = lo_dev;
+    return launch_gemm16(nullptr, (hipStream_t)stream, precision, a_dev, (layout & WM_GEMM_W_PACKED) ? nullptr : w_dev, bias_dev, nullptr, 0,
+                         nullptr, hi_dev, M, N, K, ACT_NONE, x);
+}
+
+extern "C" int wm_op_unpack16(const void* in_dev, void* out_dev, int64_t rows, int K, void* stream) {
+    if (!in_dev || !out_dev || rows <= 0 || K <= 0 || rows % 16 || K % 32) return fail("wm_op_unpack16: rows=%lld K=%d (rows %% 16, K %% 32)", (long long)rows, K);
+    hipLaunchKernelGGL(unpack16_lds_image_kernel, dim3(grid_for(rows * (K / 8))), dim3(256), 0, (hipStream_t)stream, (const uint4*)in_dev, (uint4*)out_dev, rows, K);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int wm_op_fold_weight16(const void* w16_dev, const float* gamma_dev, const float* beta_dev, const float* bias_dev, void* wf_dev,
                                    float* c1_dev, float* c2_dev, int N, int K, int precision, void* stream) {
     if (!w16_dev || !gamma_dev || !beta_dev || !wf_dev || !c1_dev || !c2_dev) return fail("wm_op_fold_weight16: null buffer");
     if (N <= 0 || K <= 0 || N % 16 || K % 32) return fail("wm_op_fold_weight16: N=%d K=%d (N %% 16, K %% 32)", N, K);
     if (precision == WM_PREC_FP16)
-        hipLaunchKernelGGL(fold_weight_kernel<FP16>, dim3(N), dim3(256), 0, (hipStream_t)stream, (const u16*)w16_dev, gamma_dev, beta_dev, bias_dev, (u16*)wf_dev, c1_dev, c2_dev, N, K);
+        hipLaunchKernelGGL(fold_weight_kernel<FP16>, dim3(N), dim3(256), 0, (hipStream_t)stream, (const u16*)w16_dev, (const float*)nullptr, gamma_dev, beta_dev, bias_dev, (u16*)wf_dev, c1_dev, c2_dev, N, K);
     else if (precision == WM_PREC_BF16)
-        hipLaunchKernelGGL(fold_weight_kernel<BF16>, dim3(N), dim3(256), 0, (hipStream_t)stream, (const u16*)w16_dev, gamma_dev, beta_dev, bias_dev, (u16*)wf_dev, c1_dev, c2_dev, N, K);
+        hipLaunchKernelGGL(fold_weight_kernel<BF16>, dim3(N), dim3(256), 0, (hipStream_t)stream, (const u16*)w16_dev, (const float*)nullptr, gamma_dev, beta_dev, bias_dev, (u16*)wf_dev, c1_dev, c2_dev, N, K);
     else return fail("wm_op_fold_weight16: precision %d", precision);
     HIP_TRY(hipGetLastError());
     return 0;

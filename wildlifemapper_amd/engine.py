@@ -33,7 +33,8 @@ class EngineHub:
             raise ValueError(f"unknown precision {self.precision!r} (bf16 | fp16 | fp8)")
         self.max_batch = int(max_batch or os.environ.get("WM_MAX_BATCH", 0) or 0)
         # folded LayerNorm (wm_config.flags & WM_CFG_FOLD_LN): True (default; WM_LN_FOLD=0 turns it off) = the fp16-operand blocks,
-        # "all" (WM_LN_FOLD=2) = bf16-operand blocks too; set before the first forward
+        # "all" (WM_LN_FOLD=2) = bf16-operand blocks too (faster, but a different draw of bf16's ~1e-3 logits error: include/wm_hip.h);
+        # set before the first forward
         self.fold_ln = {"0": False, "2": "all"}.get(os.environ.get("WM_LN_FOLD", "1"), True)
         self.fp8_gemms = 0                                         # wm_config.fp8_gemms (0 = library default); set_fp8_gemms()
         self._watch = []                                           # (owner dict, key, tensor, signature): fast no-change check
@@ -45,6 +46,7 @@ class EngineHub:
     # -- registration -------------------------------------------------------
     def register(self, prefix: str, module: torch.nn.Module) -> None:
         self._sources[prefix] = module
+        self._watch = []                                    # a module added after a forward: full walk at the next call
 
     def adopt(self, other: "EngineHub") -> None:
         """Merge the modules of another hub into this one (MedSAM wiring)."""
@@ -53,6 +55,7 @@ class EngineHub:
         for prefix, mod in other._sources.items():
             self._sources[prefix] = mod
             mod._hub = self
+        self._watch = []
         other.close()
 
     # -- handle lifetime ----------------------------------------------------
@@ -85,8 +88,10 @@ class EngineHub:
             self.close()
 
     def invalidate(self) -> None:
-        """Force a full weight walk at the next call (after replacing a whole sub-module of a registered model; replaced
-        or in-place-modified Parameters and buffers are noticed without it)."""
+        """Force a full weight walk at the next call.  Needed after writes that bypass autograd's version counter
+        (`p.data.copy_()`, `p.data.add_()`: `p._version` does not move).  Noticed without it: a replaced Parameter / buffer,
+        an in-place op on the Parameter itself (`p.mul_()`, `load_state_dict`), a swapped sub-module, a module registered
+        or adopted after a forward."""
         self._watch = []
 
     def _create(self, device: torch.device, batch: int) -> None:
@@ -117,7 +122,7 @@ class EngineHub:
         if not self._watch:
             return False
         for owner, key, t, sig in self._watch:
-            if owner.get(key) is not t or (t.data_ptr(), t._version) != sig:
+            if owner.get(key) is not t or (sig is not None and (t.data_ptr(), t._version) != sig):
                 return False
         return True
 
@@ -129,6 +134,11 @@ class EngineHub:
                     for key, t in owner.items():
                         if t is not None:
                             self._watch.append((owner, key, t, (t.data_ptr(), t._version)))
+                # the identity of every child: a swapped sub-module (`blocks[i] = new`) leaves the OLD module's dicts
+                # unchanged, so the parent's slot is watched too (signature None = identity only)
+                for key, child in sub._modules.items():
+                    if child is not None:
+                        self._watch.append((sub._modules, key, child, None))
 
     def _sync_weights(self) -> None:
         if self._unchanged():
@@ -175,6 +185,7 @@ class EngineHub:
         B = x.shape[0]
         h = self.handle(x.device, B)
         out = torch.empty((B, 256, 64, 64), device=x.device, dtype=torch.float32)
+        self._warn_overflow()
         N.check(N.lib().wm_encoder_forward(h, N.ptr(x), N.ptr(x_hfc), N.ptr(out), B, N.stream_ptr(x.device)))
         return out
 
@@ -201,11 +212,23 @@ class EngineHub:
         ts = None
         if target_sizes is not None:
             ts = target_sizes.to(device=x.device, dtype=torch.float32).contiguous()
+        self._warn_overflow()
         N.check(N.lib().wm_forward(h, N.ptr(x), N.ptr(ts), N.ptr(logits), N.ptr(boxes), N.ptr(rec), B, N.stream_ptr(x.device)))
         out = {"pred_logits": logits, "pred_boxes": boxes}
         if want_records:
             out["records"] = rec
         return out
+
+    def stream_overflow(self, reset: bool = False) -> bool:
+        """True if a value of the residual stream reached the fp16 clamp (|x| >= 65504) in a forward that has finished
+        (wm_stream_overflow; no synchronisation)."""
+        return self._handle is not None and bool(N.lib().wm_stream_overflow(self._handle, int(reset)))
+
+    def _warn_overflow(self) -> None:
+        if self.stream_overflow(reset=True):
+            import warnings
+            warnings.warn("wildlifemapper_amd: residual-stream values reached the fp16 clamp (|x| >= 65504) in an earlier forward; "
+                          "this checkpoint needs precision='bf16' (WM_PRECISION=bf16)", RuntimeWarning, stacklevel=3)
 
     # -- taps / profiling ---------------------------------------------------
     def set_tap(self, which: int) -> None:
