@@ -242,7 +242,8 @@ int wm_profile_read(wm_handle* h, wm_kclass_stat* out /* [WM_KCLASS_COUNT] */);
 #define WM_GEMM_V5_256_FOLDP 14
 #define WM_GEMM_V5_320_SPLIT 15 /* gemm16v5_kernel<320> split-stream producer: residual planes (hi, lo) in and out, row statistics (round 4) */
 #define WM_GEMM_V5_256_SPLIT 16
-#define WM_GEMM_VARIANT_COUNT 17
+#define WM_GEMM_V3_PATCH 17     /* gemm16v3_kernel AMODE 2: implicit-GEMM 16x16 / stride-16 patch embed (round 4) */
+#define WM_GEMM_VARIANT_COUNT 18
 int wm_debug_gemm_variant_counts(int64_t* out /* [WM_GEMM_VARIANT_COUNT] */, int n);
 int wm_debug_reset_gemm_variant_counts(void);
 
@@ -343,6 +344,12 @@ int wm_op_cvt_f32_to_fp8(const float* in_dev, void* out_dev, int64_t n, void* st
  * w [c_out][ky*3+kx][c_in] 16-bit (packed tap-major), out [B*4096, c_out] fp32.  c_out % 256 == 0, c_in % 32 == 0. */
 int wm_op_conv3x3_16(const void* a_dev, const void* w_dev, float* out_dev, int batch, int c_out, int c_in,
                      int precision, void* stream);
+
+/* 16 x 16 / stride-16 patch embedding (PatchEmbed / HfcEmbed, image_encoder.py:386-450) as an implicit GEMM, no im2col buffer:
+ * img16 [batch][c_in][1024][1024] 16-bit NCHW, w [n_out][c_in * 256] 16-bit row-major (Conv2d weight flattened), bias fp32 or
+ * NULL; out [batch * 4096][n_out] token-major, fp32 and / or 16-bit.  n_out % 320 == 0 or % 256 == 0. */
+int wm_op_patch_embed16(const void* img16_dev, const void* w_dev, const float* bias_dev, float* out_f32_dev, void* out_16_dev,
+                        int batch, int n_out, int c_in, int precision, void* stream);
 
 /* fp32 GEMM on the fp32-input MFMA, same contract (act 3 = sigmoid). */
 int wm_op_gemm32(const float* a_dev, const float* w_dev, const float* bias_dev,

@@ -160,6 +160,17 @@ def unpack16(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def patch_embed16(img16, w16, bias, prec="fp16", want32=True):
+    """16 x 16 / stride-16 patch embed as an implicit GEMM: img16 (B, Cin, 1024, 1024) 16-bit, w16 (N, Cin * 256) -> (B * 4096, N)."""
+    code, dt = PRECS[prec]
+    B, Cin = img16.shape[0], img16.shape[1]
+    Nn = w16.shape[0]
+    o32 = torch.empty((B * 4096, Nn), device=img16.device, dtype=torch.float32) if want32 else None
+    o16 = torch.empty((B * 4096, Nn), device=img16.device, dtype=dt)
+    N.check(N.lib().wm_op_patch_embed16(N.ptr(img16.contiguous()), N.ptr(w16), N.ptr(bias), N.ptr(o32), N.ptr(o16), B, Nn, Cin, code, sp()))
+    return o32, o16
+
+
 def gemm32(a, w, bias=None, residual=None, act=0):
     M, K = a.shape
     Nn = w.shape[0]

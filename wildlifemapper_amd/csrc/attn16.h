@@ -42,6 +42,8 @@ struct AttnArgs {
     const float* qkv_bias;                          // window kernel: [3*D] fp32 (padded tokens)
     const u16* qkv_bias16;                          // the same, rounded to the operand type: a padded token's K / V row
     int heads;
+    // q carries scale * log2(e) ("Scores" below): the engine folds it into the q rows of the qkv weight (one rounding, as before); the
+    // single-op entry points scale a copy of q first (scale_q16_kernel, one more rounding)
     unsigned char* out8;                            // WM_PREC_FP8: write the output as e4m3 bytes (row stride out_stride bytes) instead of 16-bit
 #if WM_DEV_TIMELINE
     unsigned long long* tl;                         // dev build: s_memtime stamps of workgroup 0 ([wave][64]) or null
@@ -81,11 +83,11 @@ __device__ __forceinline__ typename T::vec8 lds_read_vT(const char* p_first, int
 
 // Online-softmax state of one wave (32 queries, lane = query column + 32*half).
 template <int NDT> struct SoftmaxState {
-    float m;          // running max (log2 domain)
+    float m;          // reference point of the exponentials (log2 domain); scores reach the softmax RELATIVE to it (see "Scores" below)
     float l;          // running sum, this lane's half of the keys only
     f32x16 o[NDT];    // O^T accumulators
     __device__ __forceinline__ void init() {
-        m = -1e30f; l = 0.f;
+        m = 0.f; l = 0.f;
 #pragma unroll
         for (int i = 0; i < NDT; ++i)
 #pragma unroll
@@ -93,52 +95,112 @@ template <int NDT> struct SoftmaxState {
     }
 };
 
-// One key tile of NT*32 keys.  s[t] hold the raw accumulators; the log2-domain score of an element is
-// c1 * (s + tile_bias) (c1 = softmax scale * log2 e; tile_bias = a per-query constant of this tile, e.g. the
-// rel-pos kh-term divided by the scale).  kvalid: number of valid keys in the tile (keys >= kvalid are masked).
-// sV: LDS address of the tile's V rows.
-// VALU budget per score (this loop is VALU-bound next to 22 MFMAs per tile): max, one FMA folding scale, bias and
-// running max into the exp2 argument, exp2, sum, convert.  The O accumulators are rescaled only when the running
-// max grew by more than RESCALE_THR (log2 units), so most tiles skip the O-wide multiply; until then P values are
-// bounded by 2^RESCALE_THR instead of 1, harmless in fp32 accumulators and for 16-bit floating P.
+// Scores (round 4).  Q reaches the kernels multiplied by c1 = softmax scale * log2 e (folded into the q rows of the qkv weight
+// before its one rounding; AttnArgs::q_prescaled), so the QK^T accumulators ARE the log2-domain scores, and everything that used to
+// be added per score on the vector pipe rides the matrix pipe instead:
+//   - the kw rel-pos term: the accumulators' initial value (as before);
+//   - the per-(query, key tile) scalars -- the kh rel-pos term and minus the reference point m -- through ONE extra 16-deep k-step
+//     of the QK^T product: B[k][query] holds the scalar as a (hi, lo) pair of 16-bit values (22 / 16 significant bits), A[key][k] is
+//     1.0 at that pair's two k positions and 0 elsewhere, the same for every key of the tile (bias_a_frag / bias_b_*).  A B
+//     fragment carries the pairs of 8 consecutive tiles (4 per lane half) and is rebuilt every 8 tiles and when m moves.
+// The softmax is then max (the deferred-rescale check), exp2 of the accumulator itself, convert: the FMA per score is gone
+// (32 of ~116 vector instructions per 64-key tile in the global kernel).  m moves only when some query's maximum exceeds it by more
+// than RESCALE_THR (log2 units) -- and at the first tile, where it becomes that tile's maximum -- so P <= 2^RESCALE_THR: harmless in
+// fp32 accumulators and for 16-bit floating P.  When it moves, the tile's scores are corrected on the vector pipe (rare).
 constexpr float RESCALE_THR = 6.0f;
 
+template <class T> __device__ __forceinline__ unsigned one_pair_bits() {
+    return std::is_same<T, FP16>::value ? 0x3C003C00u : 0x3F803F80u;           // (1.0, 1.0) as two 16-bit floats
+}
+// A fragment of the bias k-step for a lane holding k = 8 h .. 8 h + 7: 1.0 at k = 2 pos, 2 pos + 1 if `mine`, else 0
+template <class T>
+__device__ __forceinline__ typename T::vec8 bias_a_frag(int pos, bool mine) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 a;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) a[d] = (mine && d == pos) ? one_pair_bits<T>() : 0u;
+    return __builtin_bit_cast(typename T::vec8, a);
+}
+template <class T>
+__device__ __forceinline__ void hi_lo(float v, typename T::elem& hi, typename T::elem& lo) {
+    hi = T::from_f32(v);
+    lo = T::from_f32(v - T::to_f32(hi));
+}
+// B fragment, no per-tile term: (hi, lo) of `v` at k = 0, 1 (lanes of half 0; bias_a_frag(0, h == 0) selects them)
+template <class T>
+__device__ __forceinline__ typename T::vec8 bias_b_const(float v) {
+    typename T::vec8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = T::from_f32(0.f);
+    typename T::elem hi, lo;
+    hi_lo<T>(v, hi, lo);
+    b[0] = hi; b[1] = lo;
+    return b;
+}
+// B fragment with the kh rel-pos term: lane (c, h) holds the pairs of tiles (j & ~7) + 4 h + i, i = 0..3, each rel_h[tile][c] - m
+// (tile j is selected by bias_a_frag(j & 3, h == ((j >> 2) & 1))); rel_h: [tile][32 queries] fp32 in LDS
+template <class T>
+__device__ __forceinline__ typename T::vec8 bias_b_rel(const float* rel_h, int j, int c, int h, float m, int ntiles) {
+    typename T::vec8 b;
+    const int j0 = (j & ~7) + 4 * h;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = rel_h[min(j0 + i, ntiles - 1) * 32 + c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        typename T::elem hi, lo;
+        hi_lo<T>(v[i] - m, hi, lo);
+        b[2 * i] = hi; b[2 * i + 1] = lo;
+    }
+    return b;
+}
+// q -> c1 q for callers that hold the reference's plain q (the single-op entry points): out[row][0..cols) = round16(c1 * in[row][0..cols))
+template <class T>
+__global__ __launch_bounds__(256) void scale_q16_kernel(const u16* __restrict__ in, int in_stride, u16* __restrict__ out, int64_t rows, int cols, float c1) {
+    const int cpr = cols / 8;
+    const int64_t n = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / cpr;
+        const int ch = (int)(i - row * cpr);
+        typename T::vec8 v = *(const typename T::vec8*)(in + row * in_stride + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = T::from_f32(T::to_f32(v[j]) * c1);
+        *(typename T::vec8*)(out + row * cols + ch * 8) = v;
+    }
+}
+
+// One key tile of NT*32 keys (4-wave kernel): s[t] hold the log2-domain scores without the tile's scalar `tile_bias` (the kh rel-pos
+// term, 0 without rel-pos) and without the reference point: both are added per score here (one v_add in front of the exp2).  The
+// 8-wave kernel's non-rel-pos instances move that add to the matrix pipe (bias k-step, "Scores"); for this kernel's shapes it measured
+// slower (head_dim 128: 1257 vs 1190 us, 34 MFMAs per tile against a vector phase that is already the shorter one).  sV: the tile's V rows.
 template <class T, int HD, int NT>
-__device__ __forceinline__ void softmax_pv(SoftmaxState<AttnGeom<HD>::NDT>& st, f32x16 (&s)[NT],
-                                           float c1, float tile_bias, int kvalid, const char* sV, int lane) {
+__device__ __forceinline__ void softmax_pv(SoftmaxState<AttnGeom<HD>::NDT>& st, f32x16 (&s)[NT], bool first, float tile_bias, const char* sV, int lane) {
     using G = AttnGeom<HD>;
-    const int h = lane >> 5;
-    float mx = -1e30f;
+    float mx0 = -1e30f, mx1 = -1e30f;                       // two chains: a dependent v_max3 issues every ~8 cycles, not 4
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (key >= kvalid) s[t][r] = -1e30f;          // folds away when the tile is full
-            mx = fmaxf(mx, s[t][r]);
-        }
-    mx = (mx + tile_bias) * c1;
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // defer-max: keep the old reference point unless some query's max grew by more than the threshold
-    float m_use = st.m;
-    if (!__all(mx - st.m <= RESCALE_THR)) {
-        const float m_new = fmaxf(st.m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(st.m - m_new);
+    for (int r = 0; r < 16; ++r) { mx0 = fmaxf(mx0, s[0][r]); mx1 = fmaxf(mx1, s[NT - 1][r]); }
+    float mx = fmaxf(mx0, mx1) + (tile_bias - st.m);        // this tile's maximum relative to the reference point (same association as attn_glob8.h)
+    {   // the other half of the keys sits in lane ^ 32
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    if (first || !__all(mx <= RESCALE_THR)) {
+        const float d = first ? mx : fmaxf(mx, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d);
         st.l *= alpha;
 #pragma unroll
         for (int dt = 0; dt < G::NDT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
-        st.m = m_new;
-        m_use = m_new;
+        st.m += d;
     }
-    const float off = tile_bias * c1 - m_use;
+    const float off = tile_bias - st.m;
     float ls = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][r], c1, off));
+            const float pv = __builtin_amdgcn_exp2f(s[t][r] + off);
             s[t][r] = pv;
             if constexpr (!G::LSUM_IN_O) ls += pv;      // else: row HD of O^T accumulates the sum (V pad column = 1)
         }
@@ -279,13 +341,12 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int head = (lid / nqb) % p.heads, b = lid / (nqb * p.heads);
     const int q0 = (lid % nqb) * 128 + wave * 32;
-    const float c1 = p.scale * 1.44269504088896340736f;
 
     const u16* qb = p.q + ((size_t)b * p.nq) * p.q_stride + head * HD;
     const u16* kb = p.k + ((size_t)b * p.nk) * p.k_stride + head * HD;
     const u16* vb = p.v + ((size_t)b * p.nk) * p.v_stride + head * HD;
 
-    // Q fragments (B operand): lane holds Q[q0+c][16ks + 8h .. +7]
+    // Q fragments (B operand): lane holds Q[q0+c][16ks + 8h .. +7], in the log2 domain (see "Scores")
     typename T::vec8 qf[G::NKS];
 #pragma unroll
     for (int ks = 0; ks < G::NKS; ++ks)
@@ -435,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
         f32x16 s[2];
         float rh = 0.f;
         if constexpr (REL) {
-            rh = sRelH[j * 32 + c];                       // kh-term: one scalar per query and tile, applied inside the exp2 FMA
+            rh = sRelH[j * 32 + c];                       // kh-term: one scalar per query and tile, added in front of the exp2
 #pragma unroll
             for (int t = 0; t < 2; ++t) s[t] = relw[t];    // kw-term: the accumulators' initial value
         } else {
@@ -445,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void attn_global_kernel(AttnArgs p) {
                 for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
         }
         qk_tile<T, HD, 2>(s, qf, sK, lane);
-        softmax_pv<T, HD, 2>(st, s, c1, rh, 64, sV, lane);
+        softmax_pv<T, HD, 2>(st, s, j == 0, rh, sV, lane);
         if (j + 1 < ntiles) commit(buf ^ 1);
         __syncthreads();
     }
@@ -487,7 +548,6 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int D = p.heads * HD;
-    const float c1 = p.scale * 1.44269504088896340736f;
     const float inv_scale = 1.0f / p.scale;
 
     char* sK = smem + L::K_OFF;
@@ -569,6 +629,7 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
         for (int ks = 0; ks < G::NKS; ++ks) qf[ks] = *(const typename T::vec8*)(src + 16 * ks + 8 * h);
     };
 
+
     // rel-pos tables: the same for every item of this launch
     for (int e = tid; e < 64 * (HD / 4); e += NTHR) {
         const int row = e / (HD / 4), c4 = e % (HD / 4);
@@ -590,6 +651,7 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
     commit_kv();
 #pragma unroll
     for (int ks = 0; ks < G::NKS; ++ks) asm volatile("" : "+v"(qf[ks]));      // landed before the loop, as at its back edge (below)
+
     v_pad_ones<T, HD>(sV, L::NKEY, tid, NTHR);            // the staging never touches the pad columns again
     __syncthreads();
 
@@ -653,14 +715,12 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
             const int kw0 = (i8 & 3) + 8 * (i8 >> 2);                              // half 0; half 1: + 4
             Vsel[i8] = h ? (kw0 + 4 < WS ? V[kw0 + 4 < WS ? kw0 + 4 : 0] : -1e30f) : V[kw0 < WS ? kw0 : 0];
         }
-#ifndef WM_WIN_PIPELINED
-#define WM_WIN_PIPELINED 1
-#endif
-#if WM_WIN_PIPELINED
         // Key loop in 7 half-steps of 32 keys (two kh rows), software-pipelined inside the wave: QK^T of half-step i + 1 is ISSUED
         // before the exponentials of half-step i, so the matrix pipe works under this wave's own softmax (the two waves of a SIMD
         // overlap only by chance: timeline, 7k cycles of key loop per wave, 14k of a 17k-cycle item on a two-wave SIMD).  Two score
         // tiles of 16 registers alternate -- the same 32 registers the 64-key step held.
+        // Scores are log2-domain and relative to st.m (attn16.h "Scores"): q carries c1, and -m rides in the kw bias registers (Vsel),
+        // i.e. in the accumulators' initial value, so a probability is exp2 of the accumulator itself (no FMA per score).
         {
             f32x16 sp[2][1];
             auto s_init = [&](f32x16& d, int i) {
@@ -674,27 +734,33 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
                 f32x16& cur = sp[i & 1][0];
-                float mx = -1e30f;
+                float mx0 = -1e30f, mx1 = -1e30f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cur[r]);
-                mx *= c1;
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                float m_use = st.m;
-                if (!__all(mx - st.m <= RESCALE_THR)) {
-                    const float m_new = fmaxf(st.m, mx);
-                    const float alpha = __builtin_amdgcn_exp2f(st.m - m_new);
-                    st.l *= alpha;
+                for (int r = 0; r < 8; ++r) { mx0 = fmaxf(mx0, cur[r]); mx1 = fmaxf(mx1, cur[8 + r]); }
+                float mx = fmaxf(mx0, mx1);
+                {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                    mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                }
+                if (i == 0 || !__all(mx <= RESCALE_THR)) {          // the reference point moves: first half-step, or a maximum grew past the threshold
+                    const float d = i == 0 ? mx : fmaxf(mx, 0.f);
+                    if (i > 0) {
+                        const float alpha = __builtin_amdgcn_exp2f(-d);
+                        st.l *= alpha;
 #pragma unroll
-                    for (int dt = 0; dt < G::NDT; ++dt)
+                        for (int dt = 0; dt < G::NDT; ++dt)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
-                    st.m = m_new;
-                    m_use = m_new;
+                            for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
+                    }
+                    st.m += d;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cur[r] -= d;
+#pragma unroll
+                    for (int i8 = 0; i8 < 8; ++i8) Vsel[i8] -= d;   // the following half-steps start from the new reference point
                 }
                 // From here the order is written out and fenced (sched_barrier): left alone, hipcc clusters the 16 exponentials and
                 // puts all 11 MFMAs behind them.  QK^T(i + 1): one MFMA, then three or four scores' exponentials, five times; then
                 // P V(i): one MFMA per ~4 vector instructions (the converts of the second P fragment, the next tile's bias sums).
-                const float off = -m_use;
                 float ls = 0.f;
                 const bool more = i + 1 < 7;
                 f32x16& nxt = sp[(i + 1) & 1][0];
@@ -713,7 +779,7 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = ks * EPG; r < min(16, (ks + 1) * EPG); ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(fmaf(cur[r], c1, off));
+                        const float pv = __builtin_amdgcn_exp2f(cur[r]);
                         cur[r] = pv;
                         if constexpr (!G::LSUM_IN_O) ls += pv;
                     }
@@ -746,26 +812,6 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
                 if (i == 1 || i == 3 || i == 5) WM_WIN_STAMP(3 + i / 2);
             }
         }
-#else
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            f32x16 s[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[t][r] = U[4 * j + 2 * t + (r >> 3)] + Vsel[(r & 3) + 4 * ((r >> 2) & 1)];
-            qk_tile<T, HD, 2>(s, qf, sK + j * 64 * G::KS, lane);
-            softmax_pv<T, HD, 2>(st, s, c1, 0.f, 64, sV + j * 64 * G::VS, lane);
-            WM_WIN_STAMP(3 + j);
-        }
-        {
-            f32x16 s[1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[0][r] = U[12 + (r >> 3)] + Vsel[(r & 3) + 4 * ((r >> 2) & 1)];
-            qk_tile<T, HD, 1>(s, qf, sK + 192 * G::KS, lane);
-            softmax_pv<T, HD, 1>(st, s, c1, 0.f, 32, sV + 192 * G::VS, lane);
-        }
-#endif
         {
             int b, win, head;
             decode(item, b, win, head);
@@ -797,6 +843,7 @@ __global__ __launch_bounds__(448, 2) void attn_window_kernel(AttnArgs p, int nit
         // item's K / V prefetch in the in-order counter -- the whole prefetch latency exposed at every item start (timeline: 3-4k cycles)
 #pragma unroll
         for (int ks = 0; ks < G::NKS; ++ks) { qf[ks] = qn[ks]; asm volatile("" : "+v"(qf[ks])); }
+    
         item = next;
         __syncthreads();
         WM_WIN_STAMP(10);

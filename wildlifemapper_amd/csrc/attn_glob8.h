@@ -93,7 +93,6 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int head = (lid / nqb) % p.heads, b = lid / (nqb * p.heads);
     const int q0 = (lid % nqb) * 256 + wave * 32;
-    const float c1 = p.scale * 1.44269504088896340736f;
 
     const u16* qb = p.q + ((size_t)b * p.nq) * p.q_stride + head * HD;
     const u16* kb = p.k + ((size_t)b * p.nk) * p.k_stride + head * HD;
@@ -279,6 +278,16 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
     st.init();
     f32x16 s[NT];
     typename T::vec8 pb[2 * NT];                            // P^T fragments of the tile last softmax-ed
+    // the bias k-step's B fragment (attn16.h "Scores"): -m and, with REL, the kh rel-pos terms of 8 tiles; rebuilt every 8 tiles
+    // (matrix phase, in front of the tile's QK^T) and when m moves (vector phase, for the next tile's QK^T)
+    // (REL instances add their per-tile scalar -- the kh rel-pos term minus m -- per score on the vector pipe instead: with 24 MFMAs
+    // per tile the matrix phase became the longer one, 1676 vs 1640 us per launch at B = 16; head_dim 128 without rel-pos gained
+    // 14 %, 1257 -> 1086 us, and moved from the 4-wave kernel to this one)
+    typename T::vec8 bx;
+    auto rebuild = [&]() {
+        if constexpr (!REL) bx = bias_b_const<T>(-st.m);
+    };
+    rebuild();
 
 #if WM_DEV_TIMELINE
     // dev: stamps of workgroup 0, per wave, tiles 4..8, 12 per tile: 0 V start, 1 row max known, 2 P built, 3 staging committed, 4 next loads
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
         const int r31 = lane & 31;
         constexpr int AHEAD = 2;                             // fragments requested ahead of the MFMA that consumes them (2..8 and
                                                              // s_setprio 3 around the phase: all within 1 %)
-        constexpr int NF_PV = 2 * NT * G::NDT, NF_QK = G::NKS * NT;
+        constexpr int NF_PV = 2 * NT * G::NDT, NF_QK = G::NKS * NT;                  // fragments read from LDS (the bias k-step's NT MFMAs read none)
         auto pv_body = [&]() {
             const unsigned vbase = lds_base_opaque(sV + v_lane_off);
 #pragma unroll
@@ -343,6 +352,11 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
                     typename T::vec8 kf = lds_read_v8_at<T>(kbase, 32 * t * G::KS + 32 * ks);
                     s[t] = T::mfma32(kf, qf[ks], s[t]);
                 }
+            if constexpr (!REL) {                            // the bias k-step: -m from the matrix pipe (attn16.h "Scores")
+                const typename T::vec8 ax = bias_a_frag<T>(0, h == 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) s[t] = T::mfma32(ax, bx, s[t]);
+            }
         };
         // instruction order of a run of fragments: AHEAD fragments' reads first (a V^T fragment is 2 transposed reads, a K fragment
         // 1), then one MFMA per further fragment's reads -- across the P V / QK^T seam too, so the QK^T reads are not a second exposed
@@ -357,6 +371,7 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
                 if (f + AHEAD < NF_PV) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 else if (f + AHEAD < NF_PV + NF_QK) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
+            if constexpr (!REL) __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
         } else if constexpr (pv) {
             pv_body();
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * AHEAD, 0);
@@ -373,6 +388,7 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (f + AHEAD < NF_QK) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
+            if constexpr (!REL) __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
         }
         WM_G8_STAMP(6, j - 1);
         if constexpr (qk) {
@@ -388,7 +404,8 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
         float mx0 = -1e30f, mx1 = -1e30f;                   // two chains: a dependent v_max3 issues every ~8 cycles, not 4
 #pragma unroll
         for (int r = 0; r < 16; ++r) { mx0 = fmaxf(mx0, s[0][r]); mx1 = fmaxf(mx1, s[NT - 1][r]); }
-        float mx = (fmaxf(mx0, mx1) + rh) * c1;
+        float mx = fmaxf(mx0, mx1);
+        if constexpr (REL) mx = mx + (rh - st.m);           // REL: the scores lack the kh term and the reference point; !REL: they are relative already
         {   // the other half of the keys sits in lane ^ 32: v_permlane32_swap (vector pipe) instead of ds_bpermute (an LDS round trip)
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -397,25 +414,32 @@ __global__ __launch_bounds__(512, 2) void attn_global8_kernel(AttnArgs p) {
         asm volatile("" : "+v"(mx));
         WM_G8_STAMP(1, j);
 #endif
-        float m_use = st.m;
-        if (!__all(mx - st.m <= RESCALE_THR)) {
-            const float m_new = fmaxf(st.m, mx);
-            const float alpha = __builtin_amdgcn_exp2f(st.m - m_new);
+        // the reference point st.m moves at the first tile and when a maximum grew past the threshold (attn16.h "Scores")
+        if (j == 0 || !__all(mx <= RESCALE_THR)) {
+            const float d = j == 0 ? mx : fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-d);
             st.l *= alpha;
 #pragma unroll
             for (int dt = 0; dt < G::NDT; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st.o[dt][r] *= alpha;
-            st.m = m_new;
-            m_use = m_new;
+            st.m += d;
+            if constexpr (!REL) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[t][r] -= d;
+                rebuild();
+            }
         }
-        const float off = rh * c1 - m_use;
+        const float off = REL ? rh - st.m : 0.f;           // REL: added inside the exp2 expression (hipcc then alternates v_add / v_exp; as a
+                                                            // separate loop it emitted 32 adds, then 32 exps: +5 % on the kernel)
         float ls = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][r], c1, off));
+                const float pv = REL ? __builtin_amdgcn_exp2f(s[t][r] + off) : __builtin_amdgcn_exp2f(s[t][r]);
                 s[t][r] = pv;
                 if constexpr (!G::LSUM_IN_O) ls += pv;
             }

@@ -111,8 +111,12 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* __restrict__ R, c
 }
 
 // K3: inverse row transform of the 362 kept columns, out = |gray - Re(.)/N^2|.  grid (1024, B).
+// x16 / hfc16 (optional): 16-bit NCHW copies of the three input channels and of the result, for the im2col-free patch embeds
+// (gemm16_v3.h AMODE 2) -- this pass has both values in registers anyway.
+template <class T>
 __global__ __launch_bounds__(256) void fft_rows_inv_kernel(const float* __restrict__ x, const float2* __restrict__ R,
-                                                           const float2* __restrict__ tw, float* __restrict__ out) {
+                                                           const float2* __restrict__ tw, float* __restrict__ out,
+                                                           u16* __restrict__ x16, u16* __restrict__ hfc16) {
     __shared__ float2 sA[FFT_N], sB[FFT_N];
     const int j = threadIdx.x, y = blockIdx.x;
     const int64_t b = blockIdx.y;
@@ -128,7 +132,15 @@ __global__ __launch_bounds__(256) void fft_rows_inv_kernel(const float* __restri
     for (int r = 0; r < 4; ++r) {
         const int col = j + r * 256;
         const float g = gray_of(x, b, y, col);
-        out[(b * FFT_N + y) * (int64_t)FFT_N + col] = fabsf(g - res[col].x * norm);
+        const float o = fabsf(g - res[col].x * norm);
+        out[(b * FFT_N + y) * (int64_t)FFT_N + col] = o;
+        if (x16) {
+            const float* px = x + ((b * 3) * FFT_N + y) * (int64_t)FFT_N + col;
+            typename T::elem* d = (typename T::elem*)x16 + ((b * 3) * FFT_N + y) * (int64_t)FFT_N + col;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c * (int64_t)FFT_N * FFT_N] = T::from_f32(px[c * (int64_t)FFT_N * FFT_N]);
+            ((typename T::elem*)hfc16)[(b * FFT_N + y) * (int64_t)FFT_N + col] = T::from_f32(o);
+        }
     }
 }
 

@@ -18,6 +18,8 @@
 //   K-step 32: LDS rows are 64 B; 3-slot ring of (256 + BN) x 64 B (108 KiB at BN = 320).
 //   DMA piece = 16 rows x 64 B; swizzle phys_chunk = chunk ^ ((-(row >> 2)) & 3) on the SOURCE address and
 //   on the ds_read_b128 address (conflict-free lane groups).
+//   AMODE 2 (round 4; im2col-free 16x16 / stride-16 patch embeds, image_encoder.py:386-450): the A tile is gathered from the
+//   16-bit NCHW image, see dma_a.
 //   AMODE 1 (im2col-free 3x3 conv, the neck's second conv image_encoder.py:113-119): the A tile of K-step s
 //   is the 32-channel slice ci0 = (32 s) % C of tap (32 s) / C of the NHWC activation, shifted by the tap's
 //   (dy, dx); the DMA source address is computed per lane and points at a zero page outside the image.
@@ -103,6 +105,18 @@ __global__ __launch_bounds__((G3<BN, WN>::THREADS), 2) void gemm16v3_kernel(Gemm
             const char* base = Ab + (size_t)(m0 + seg * 16) * row_bytes + (size_t)s * 64;
             if (dbg_nodma) base = Ab;
             __builtin_amdgcn_global_load_lds(base + (dbg_nodma ? (lane_off & 1023u) : lane_off), WM_LDS_PTR(smem + slot * C::STAGE + seg * 1024), 16, 0, 0);
+        } else if constexpr (AMODE == 2) {
+            // 16 x 16 / stride 16 patch embed without an im2col buffer (image_encoder.py:386-450): A[m][k] with m = (b, py, px) and
+            // k = c * 256 + ky * 16 + kx is read straight from the 16-bit NCHW image [B][conv_c][1024][1024].  K-step s covers
+            // channel s >> 3, image rows 2 (s & 7) and + 1 of the patch, all 16 kx: the lane's 16-byte chunk `ch` of the 64-byte
+            // LDS row is (ky = 2 (s & 7) + (ch >> 1), kx = 8 (ch & 1) .. + 7).  A piece's 16 rows are 16 consecutive patches of one
+            // patch row, so it reads two 512-byte runs of the image.
+            const int m = m0 + seg * 16 + (lane >> 2);
+            const int pix = m & 4095, py = pix >> 6, px = pix & 63, b = m >> 12;
+            const int ch = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+            const size_t row = ((size_t)b * p.conv_c + (s >> 3)) * 1024 + (size_t)(py * 16 + 2 * (s & 7) + (ch >> 1));
+            const char* src = Ab + (row * 1024 + (size_t)(px * 16 + (ch & 1) * 8)) * 2;
+            __builtin_amdgcn_global_load_lds(src, WM_LDS_PTR(smem + slot * C::STAGE + seg * 1024), 16, 0, 0);
         } else {
             // pixel of this lane's row; 16 consecutive rows of a piece lie in one image row (64 % 16 == 0)
             const int m = m0 + seg * 16 + (lane >> 2);

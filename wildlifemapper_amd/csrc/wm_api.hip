@@ -356,6 +356,15 @@ int launch_gemm16v2_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
     return 0;
 }
 
+// dev build only: tile-order A/B (WM_GEMM_GROUP_M = row tiles per group of the grouped order, every 256-row-tile instance)
+static inline void dev_group_m(Gemm16Args& a) {
+#if WM_DEV_TIMELINE
+    if (const char* e = getenv("WM_GEMM_GROUP_M")) { if (atoi(e) > 0) a.group_m = atoi(e); }
+#else
+    (void)a;
+#endif
+}
+
 template <class T16, int BN, int NSLOT = 3>
 int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
     using G = G3<BN, 4>;
@@ -365,9 +374,7 @@ int launch_gemm16v5_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
     count_variant(BN == 320 ? (a_in.residual ? WM_GEMM_V5_320_RES : WM_GEMM_V5_320) : (a_in.residual ? WM_GEMM_V5_256_RES : WM_GEMM_V5_256));
     const int grid = (a_in.M / 256) * (a_in.N / BN);
     Gemm16Args a = a_in;
-#if WM_DEV_TIMELINE
-    if (const char* e = getenv("WM_GEMM_GROUP_M")) { if (atoi(e) > 0) a.group_m = atoi(e); }     // dev build only: tile-order A/B
-#endif
+    dev_group_m(a);
     Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * a.M * (double)a.N * a.K,
                2.0 * ((double)a.M * a.K + (double)a.N * a.K) + (a.out32 ? 4.0 : 0.0) * a.M * a.N + (a.out16 ? 2.0 : 0.0) * a.M * a.N +
                    (a.residual ? 4.0 * (double)(a.res_mod > 0 ? a.res_mod : a.M) * a.N : 0.0));
@@ -484,7 +491,9 @@ static GemmExtra GX(const void* Wp, int a_packed = 0, int out_packed = 0) {
 static int fold_bn_for(int C) { return C % 320 == 0 ? 320 : 256; }
 
 template <class T16, int BN, bool SPLIT = false>
-int launch_gemm16v5_foldp_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
+int launch_gemm16v5_foldp_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
+    Gemm16Args a = a_in;
+    dev_group_m(a);
     using G = G3<BN, 4>;
     constexpr int LDS = 3 * G::STAGE + 32 * BN * 4;
     WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, true, false, SPLIT>, LDS));
@@ -500,7 +509,9 @@ int launch_gemm16v5_foldp_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
 }
 
 template <class T16, int BN>
-int launch_gemm16v5_foldc_t(wm_handle* h, hipStream_t s, const Gemm16Args& a) {
+int launch_gemm16v5_foldc_t(wm_handle* h, hipStream_t s, const Gemm16Args& a_in) {
+    Gemm16Args a = a_in;
+    dev_group_m(a);
     using G = G3<BN, 4>;
     constexpr int LDS = 3 * G::STAGE + 32 * BN * 4;
     WM_TRY(set_max_lds((const void*)gemm16v5_kernel<T16, BN, 3, false, false, true>, LDS));
@@ -650,6 +661,31 @@ int launch_conv3x3_16(wm_handle* h, hipStream_t s, int prec, const void* A, cons
     return 0;
 }
 
+// 16 x 16 / stride-16 patch embed as an implicit GEMM (gemm16_v3.h AMODE 2): img16 [B][Cin][1024][1024] 16-bit, W [N][Cin * 256]
+// row-major, out[M = B * 4096][N] = patches W^T + bias (+ residual[m % res_mod])  (image_encoder.py:386-450)
+int launch_patch_embed16(wm_handle* h, hipStream_t s, int prec, const void* img16, const void* W, const float* bias, const float* res, int res_mod,
+                         float* out32, void* out16, int B, int N, int Cin) {
+    const int M = B * 4096, K = Cin * 256;
+    if (B <= 0 || (N % 320 && N % 256) || Cin <= 0) return fail("patch_embed: B=%d N=%d Cin=%d unsupported (N %% 320 or N %% 256)", B, N, Cin);
+    if (!out32 && !out16) return fail("patch_embed: no output");
+    Gemm16Args a{};
+    a.A = (const u16*)img16; a.W = (const u16*)W; a.bias = bias; a.residual = res; a.out32 = out32; a.out16 = (u16*)out16;
+    a.M = M; a.N = N; a.K = K; a.res_mod = res_mod; a.act = ACT_NONE; a.conv_c = Cin;
+    count_variant(WM_GEMM_V3_PATCH);
+    Bracket br(h, s, WM_KCLASS_GEMM16, 2.0 * M * (double)N * K, 2.0 * ((double)M * K + (double)N * K) + (out32 ? 4.0 : 0.0) * M * N + (out16 ? 2.0 : 0.0) * M * N);
+#define WM_PE(T16, BN)                                                                                           \
+    do {                                                                                                         \
+        using G = G3<BN, 4>;                                                                                     \
+        WM_TRY(set_max_lds((const void*)gemm16v3_kernel<T16, BN, 4, 2>, G::LDS));                                \
+        hipLaunchKernelGGL((gemm16v3_kernel<T16, BN, 4, 2>), dim3((M / 256) * (N / BN)), dim3(G::THREADS), G::LDS, s, a); \
+    } while (0)
+    if (N % 320 == 0) { if (prec == WM_PREC_FP16) WM_PE(FP16, 320); else WM_PE(BF16, 320); }
+    else { if (prec == WM_PREC_FP16) WM_PE(FP16, 256); else WM_PE(BF16, 256); }
+#undef WM_PE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_gemm32(wm_handle* h, hipStream_t s, const float* A, const float* W, const float* bias, const float* res,
                   float* out, int M, int N, int K, int act, int lda = 0) {
     if (K % 16) return fail("gemm32: K=%d must be a multiple of 16", K);
@@ -712,9 +748,8 @@ template <class T16, int HD, bool REL>
 int launch_attn_global_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int batch, int kclass) {
     // the 8-wave anti-phase kernel (attn_glob8.h); WM_ATTN_4WAVE=1 (read once per process; A/B runs) keeps every shape on the 4-wave one
     static const bool four_wave = getenv("WM_ATTN_4WAVE") && atoi(getenv("WM_ATTN_4WAVE")) != 0;
-    // head_dim 128 (the HFC cross-attention) stays on the 4-wave kernel: 32 MFMAs against the same softmax per key tile leave the two
-    // phases unbalanced, 1227 vs 1189 us
-    if constexpr (HD <= 80)
+    // (head_dim 128, the HFC cross-attention: on the 8-wave kernel since round 4 -- with -m through the bias k-step its phases balance,
+    // 1086 vs 1257 us on the 4-wave kernel, profiles/r4_dev/attn_kernels_log2_domain.txt)
     if (a.nq % 256 == 0 && a.nk >= 128 && !four_wave) {
         using L8 = Global8Lds<HD, REL>;
         WM_TRY(set_max_lds((const void*)attn_global8_kernel<T16, HD, REL>, L8::TOTAL + (WM_DEV_TIMELINE ? 4096 : 0)));
@@ -804,9 +839,29 @@ int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
     return 0;
 }
 
+unsigned grid_for(int64_t n, int per = 256, unsigned cap = 256 * 16);
+
+// The attention kernels take q in the log2 domain, c1 q with c1 = head_dim^-0.5 * log2 e (attn16.h "Scores").  A caller that holds the
+// reference's plain q (the single-op entry points) gets a scaled copy in a scratch buffer: a.q / a.q_stride are redirected to it.
+int scale_q_copy(hipStream_t s, int prec, AttnArgs& a, int batch, int cols) {
+    const int64_t rows = (int64_t)batch * a.nq;
+    void* pb = nullptr;
+    WM_TRY(op_scratch(s, 2, (size_t)rows * cols * 2, &pb));
+    const float c1 = a.scale * 1.44269504088896340736f;
+    const dim3 grid(grid_for(rows * (cols / 8)));
+    if (prec == WM_PREC_FP16) hipLaunchKernelGGL(scale_q16_kernel<FP16>, grid, dim3(256), 0, s, a.q, a.q_stride, (u16*)pb, rows, cols, c1);
+    else hipLaunchKernelGGL(scale_q16_kernel<BF16>, grid, dim3(256), 0, s, a.q, a.q_stride, (u16*)pb, rows, cols, c1);
+    HIP_TRY(hipGetLastError());
+    a.q = (const u16*)pb;
+    a.q_stride = cols;
+    return 0;
+}
+
+// q_prescaled: q already carries softmax scale * log2 e (the engine folds it into the q rows of the qkv weight at wm_finalize_weights,
+// attn16.h "Scores"); 0 for the single-op entry points, whose callers pass the reference's plain q
 int launch_encoder_attention(wm_handle* h, hipStream_t s, int prec, const void* qkv, const float* qkv_bias,
                              const float* rel_h, const float* rel_w, void* out, int batch, int heads, int hd, int window, void* out8 = nullptr,
-                             const void* k_sep = nullptr, const void* v_sep = nullptr, int tok_stride = 0) {
+                             const void* k_sep = nullptr, const void* v_sep = nullptr, int tok_stride = 0, int q_prescaled = 0) {
     const int D = heads * hd;
     AttnArgs a{};
     a.out8 = (unsigned char*)out8;
@@ -818,6 +873,7 @@ int launch_encoder_attention(wm_handle* h, hipStream_t s, int prec, const void* 
     a.nq = a.nk = T;
     a.scale = 1.0f / sqrtf((float)hd);
     a.rel_h = rel_h; a.rel_w = rel_w; a.qkv_bias = qkv_bias; a.heads = heads;
+    if (!q_prescaled) WM_TRY(scale_q_copy(s, prec, a, batch, D));
     if (window == 0) {
         return prec == WM_PREC_FP16 ? launch_attn_global_p<FP16>(h, s, a, batch, hd, true, WM_KCLASS_ATTN_GLOBAL)
                                     : launch_attn_global_p<BF16>(h, s, a, batch, hd, true, WM_KCLASS_ATTN_GLOBAL);
@@ -848,11 +904,12 @@ int launch_encoder_attention(wm_handle* h, hipStream_t s, int prec, const void* 
 }
 
 int launch_mha16(wm_handle* h, hipStream_t s, int prec, const void* q, int qs, const void* k, int ks, const void* v, int vs,
-                 void* out, int os, int batch, int heads, int hd, int nq, int nk) {
+                 void* out, int os, int batch, int heads, int hd, int nq, int nk, int q_prescaled = 0) {
     AttnArgs a{};
     a.q = (const u16*)q; a.k = (const u16*)k; a.v = (const u16*)v; a.out = (u16*)out;
     a.q_stride = qs; a.k_stride = ks; a.v_stride = vs; a.out_stride = os;
     a.nq = nq; a.nk = nk; a.scale = 1.0f / sqrtf((float)hd); a.heads = heads;
+    if (!q_prescaled) WM_TRY(scale_q_copy(s, prec, a, batch, heads * hd));
     return prec == WM_PREC_FP16 ? launch_attn_global_p<FP16>(h, s, a, batch, hd, false, WM_KCLASS_ATTN_GLOBAL)
                                 : launch_attn_global_p<BF16>(h, s, a, batch, hd, false, WM_KCLASS_ATTN_GLOBAL);
 }
@@ -903,7 +960,7 @@ int launch_simple(wm_handle* h, hipStream_t s, double bytes, K kern, dim3 grid, 
     return 0;
 }
 
-unsigned grid_for(int64_t n, int per = 256, unsigned cap = 256 * 16) {
+unsigned grid_for(int64_t n, int per, unsigned cap) {
     int64_t g = (n + per - 1) / per;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
@@ -1220,6 +1277,25 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
         else h->dec_ready = nmiss == 0;
     }
     if (!h->enc_ready && !h->dec_ready) return fail("wm_finalize_weights: no weights loaded");
+    // Attention scores are computed in the log2 domain with the scale inside q (attn16.h "Scores"): the q rows of every qkv
+    // weight and bias (and of the HFC cross-attention's in_proj) are multiplied by head_dim^-0.5 * log2 e here, in fp32, BEFORE the one
+    // rounding to the operand type (16-bit, folded gamma (.) W, or e4m3 with its per-channel scale), so q = (c1 q_ref) costs no rounding.
+    // Each staged tensor passes here exactly once (the staging area is cleared at the end of this call).
+    {
+        const float c1_blk = (1.0f / sqrtf((float)h->hd)) * 1.44269504088896340736f;
+        const float c1_hfc = (1.0f / sqrtf((float)(HFC / HFC_HEADS))) * 1.44269504088896340736f;
+        for (auto& kv : h->staged) {
+            const std::string& name = kv.first;
+            std::vector<float>& d = kv.second.data;
+            float c1 = 0.f;
+            size_t nq = 0;                                  // leading elements that belong to q
+            if (name.rfind("image_encoder.blocks.", 0) == 0 && ends_with(name, "attn.qkv.weight")) { c1 = c1_blk; nq = (size_t)h->D * h->D; }
+            else if (name.rfind("image_encoder.blocks.", 0) == 0 && ends_with(name, "attn.qkv.bias")) { c1 = c1_blk; nq = (size_t)h->D; }
+            else if (name == "image_encoder.hfc_attn.cross_attn.in_proj_weight") { c1 = c1_hfc; nq = (size_t)HFC * HFC; }
+            else if (name == "image_encoder.hfc_attn.cross_attn.in_proj_bias") { c1 = c1_hfc; nq = (size_t)HFC; }
+            for (size_t i = 0; i < nq && i < d.size(); ++i) d[i] *= c1;
+        }
+    }
     // re-upload: free previous device copies of the tensors being replaced
     for (auto& kv : h->staged) {
         auto i16 = h->w16.find(kv.first);
@@ -1377,11 +1453,12 @@ int tap_alloc(wm_handle* h) {
     return 0;
 }
 
-int fft_impl(wm_handle* h, const float* x, float* out, int B, hipStream_t s) {
+int fft_impl(wm_handle* h, const float* x, float* out, int B, hipStream_t s, bool copies16 = false) {
     WM_TRY(launch_simple(h, s, (double)B * (12e6 + 3e6), fft_rows_fwd_kernel, dim3(FFT_N, B), dim3(256), x, h->fftR, (const float2*)h->fft_tw));
     WM_TRY(launch_simple(h, s, (double)B * 6e6, fft_cols_kernel, dim3(FFT_L, B), dim3(256), h->fftR, (const float2*)h->fft_tw));
-    WM_TRY(launch_simple(h, s, (double)B * (12e6 + 3e6 + 4e6), fft_rows_inv_kernel, dim3(FFT_N, B), dim3(256), x, (const float2*)h->fftR,
-                         (const float2*)h->fft_tw, out));
+    // copies16: the last pass also leaves fp16 NCHW copies of x and of the result in p16 / h16 (the patch embeds' operands)
+    WM_TRY(launch_simple(h, s, (double)B * (12e6 + 3e6 + 4e6 + (copies16 ? 8e6 : 0.0)), fft_rows_inv_kernel<FP16>, dim3(FFT_N, B), dim3(256), x, (const float2*)h->fftR,
+                         (const float2*)h->fft_tw, out, copies16 ? (u16*)h->p16 : (u16*)nullptr, copies16 ? (u16*)h->h16 : (u16*)nullptr));
     return 0;
 }
 
@@ -1429,19 +1506,23 @@ int sat_check(wm_handle* h, hipStream_t s, int which, const void* buf, int64_t n
     return 0;
 }
 
-int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw, int B, hipStream_t s) {
+int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw, int B, hipStream_t s, bool have16 = false) {
     const int D = h->D, M = B * T;
     const int PS = WM_PREC_FP16;      // stem, HFC adaptor and neck: fp16 operands in every mode (see is_stem_or_neck)
     const std::string e = "image_encoder.", a = e + "hfc_attn.";
     // ---- stem: patch / HFC embeds (image_encoder.py:124-128) ----
-    WM_TRY(launch_simple(h, s, B * 18.9e6, patchify_kernel<FP16>, dim3(grid_for((int64_t)B * 3 * 1024 * 256)), dim3(256), x, (u16*)h->p16, B, 3));
-    WM_TRY(launch_simple(h, s, B * 6.3e6, patchify_kernel<FP16>, dim3(grid_for((int64_t)B * 1024 * 256)), dim3(256), hfc, (u16*)h->h16, B, 1));
+    // the embeds read 16-bit NCHW copies of x and hfc (p16, h16) -- left there by the FFT's last pass (wm_forward) or made here --
+    // through the implicit-GEMM loader (gemm16_v3.h AMODE 2): no im2col buffer
+    if (!have16) {
+        WM_TRY(launch_simple(h, s, B * 18.9e6, cvt_f32_to_16_kernel<FP16>, dim3(grid_for((int64_t)B * 3 * 1024 * 256)), dim3(256), x, (u16*)h->p16, (int64_t)B * 3 * 1024 * 256));
+        WM_TRY(launch_simple(h, s, B * 6.3e6, cvt_f32_to_16_kernel<FP16>, dim3(grid_for((int64_t)B * 1024 * 256)), dim3(256), hfc, (u16*)h->h16, (int64_t)B * 1024 * 256));
+    }
     // t = patch_embed(x) + pos_embed  -> tokbase (fp32) and xn16 (16-bit copy for proj_patch)
-    WM_TRY(launch_gemm16(h, s, PS, h->p16, W16(h, e + "patch_embed.proj.weight"), W32(h, e + "patch_embed.proj.bias"),
-                         W32(h, e + "pos_embed"), T, h->tokbase, h->xn16, M, D, 768, ACT_NONE, GX(W16P(h, e + "patch_embed.proj.weight"))));
+    WM_TRY(launch_patch_embed16(h, s, PS, h->p16, W16(h, e + "patch_embed.proj.weight"), W32(h, e + "patch_embed.proj.bias"),
+                                W32(h, e + "pos_embed"), T, h->tokbase, h->xn16, B, D, 3));
     WM_TRY(do_tap(h, s, -3, B, h->tokbase));
-    WM_TRY(launch_gemm16(h, s, PS, h->h16, W16(h, e + "hfc_embed.proj.weight"), W32(h, e + "hfc_embed.proj.bias"),
-                         nullptr, 0, nullptr, h->he16, M, HFC, 256, ACT_NONE, GX(W16P(h, e + "hfc_embed.proj.weight"))));
+    WM_TRY(launch_patch_embed16(h, s, PS, h->h16, W16(h, e + "hfc_embed.proj.weight"), W32(h, e + "hfc_embed.proj.bias"),
+                                nullptr, 0, nullptr, h->he16, B, HFC, 1));
     // ---- HFC adaptor (image_encoder.py:486-516) ----
     WM_TRY(launch_gemm16(h, s, PS, h->he16, W16(h, a + "proj_hfc.weight"), W32(h, a + "proj_hfc.bias"),
                          W32(h, a + "pos_embed"), T, nullptr, h->hp16, M, HFC, HFC, ACT_NONE, GX(W16P(h, a + "proj_hfc.weight"))));                    // :494
@@ -1453,7 +1534,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     WM_TRY(launch_gemm16(h, s, PS, h->pt16, wi, bi, nullptr, 0, nullptr, h->q16, M, HFC, HFC, ACT_NONE, GX(wip)));
     WM_TRY(launch_gemm16(h, s, PS, h->hp16, wi + (size_t)HFC * HFC, bi + HFC, nullptr, 0, nullptr, h->kv16, M, 2 * HFC, HFC, ACT_NONE, GX(wip ? wip + (size_t)HFC * HFC : nullptr)));
     WM_TRY(launch_mha16(h, s, PS, h->q16, HFC, h->kv16, 2 * HFC, h->kv16 + HFC, 2 * HFC, h->aoh16, HFC, B, HFC_HEADS,
-                        HFC / HFC_HEADS, T, T));                                                                      // :500-503
+                        HFC / HFC_HEADS, T, T, 1));                                                                      // :500-503
     WM_TRY(launch_gemm16(h, s, PS, h->aoh16, W16(h, a + "cross_attn.out_proj.weight"), W32(h, a + "cross_attn.out_proj.bias"),
                          h->pt32, 0, h->y1, nullptr, M, HFC, HFC, ACT_NONE, GX(W16P(h, a + "cross_attn.out_proj.weight"))));                                       // + residual :504
     WM_TRY(launch_layernorm(h, s, PS, h->y1, W32(h, a + "norm1.weight"), W32(h, a + "norm1.bias"), 1e-5f, h->y1n32, h->y1n16, M, HFC));
@@ -1562,7 +1643,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
             WM_TRY(folded(b + "attn.qkv.weight", ACT_NONE, 0, h->qkv16, 3 * D));
             WM_TRY(sat_check(h, s, WM_SAT_QKV, h->qkv16, (int64_t)M * 3 * D, P));
             WM_TRY(launch_encoder_attention(h, s, P, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
-                                            W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14, nullptr));
+                                            W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14, nullptr, nullptr, nullptr, 0, 1));
             WM_TRY(sat_check(h, s, WM_SAT_ATTN, h->ao16, (int64_t)M * D, P));
             WM_TRY(residual_gemm(P, h->ao16, b + "attn.proj", D, 0));
             WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, P));
@@ -1586,7 +1667,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
         WM_TRY(sat_check(h, s, WM_SAT_QKV, h->qkv16, (int64_t)M * 3 * D, P));
         // the attention kernels write their output as e4m3 when proj consumes e4m3
         WM_TRY(launch_encoder_attention(h, s, P, h->qkv16, W32(h, b + "attn.qkv.bias"), W32(h, b + "attn.rel_pos_h"),
-                                        W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14, p8 ? h->ao8 : nullptr));
+                                        W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14, p8 ? h->ao8 : nullptr, nullptr, nullptr, 0, 1));
         if (p8) WM_TRY(sat_check(h, s, WM_SAT_ATTN, h->ao8, (int64_t)M * D, WM_PREC_FP8));
         else WM_TRY(sat_check(h, s, WM_SAT_ATTN, h->ao16, (int64_t)M * D, P));
         if (p8) {
@@ -1786,8 +1867,8 @@ extern "C" int wm_forward(wm_handle* h, const float* x_dev, const float* target_
     WM_TRY(check_ready(h, batch, "wm_forward", true, true));
     if (!x_dev) return fail("wm_forward: null input");
     hipStream_t s = (hipStream_t)stream;
-    WM_TRY(fft_impl(h, x_dev, h->hfc, batch, s));                                          // network.py:61
-    WM_TRY(encoder_impl(h, x_dev, h->hfc, nullptr, batch, s));                             // network.py:65
+    WM_TRY(fft_impl(h, x_dev, h->hfc, batch, s, true));                                    // network.py:61 (+ the embeds' 16-bit operands)
+    WM_TRY(encoder_impl(h, x_dev, h->hfc, nullptr, batch, s, true));                       // network.py:65
     WM_TRY(decoder_impl(h, h->emb_nhwc, h->logits, h->boxes, batch, s));                   // network.py:79-86
     const float* ts = target_sizes_dev ? target_sizes_dev : h->tsz_default;
     WM_TRY(launch_simple(h, s, 0.0, postprocess_nms_kernel, dim3(batch), dim3(64), (const float*)h->logits, (const float*)h->boxes, ts,
@@ -2035,10 +2116,31 @@ extern "C" int wm_preprocess_u8_resized(const uint8_t* img_dev, float* out_dev, 
         HIP_TRY(hipMalloc((void**)&tmp.p, need));
         tmp.bytes = need;
     }
-    hipLaunchKernelGGL(resize_h_u8_kernel, dim3(grid_for((int64_t)batch * height * ow)), dim3(256), 0, s, img_dev, tmp.p, (const int*)pl.bx,
-                       (const int*)pl.kx, pl.ksx, batch, height, width, ow);
-    hipLaunchKernelGGL(resize_v_normalize_kernel, dim3(grid_for((int64_t)batch * 1024 * 1024)), dim3(256), 0, s, (const unsigned char*)tmp.p, out_dev,
-                       (const int*)pl.by, (const int*)pl.ky, pl.ksy, batch, height, ow, oh);
+    // horizontal pass: the row-staged kernel where its geometry holds (<= 20 taps, <= 1024 output columns, a row fits LDS), else the generic one
+    const int64_t rows_total = (int64_t)batch * height;
+    const int lds_h = ((width * 3 + 3 + 3) / 4 + 1) * 4 + 64;      // row + alignment shift, + slack for the zero-coefficient taps (KMAX * 3 bytes)
+    const bool fast_h = pl.ksx <= 20 && ow <= 1024 && lds_h <= 64 * 1024 && !(getenv("WM_RESIZE_GENERIC") && atoi(getenv("WM_RESIZE_GENERIC")));
+    if (fast_h) {
+        const int rpb = (int)std::max<int64_t>(4, std::min<int64_t>(16, rows_total / (256 * 8)));     // rows per workgroup: the coefficient registers are loaded once per workgroup
+        const dim3 grid((unsigned)((rows_total + rpb - 1) / rpb));
+        const int64_t in_bytes = rows_total * width * 3;
+#define WM_RH(KM, OP) hipLaunchKernelGGL((resize_h_rows_kernel<KM, OP>), grid, dim3(256), lds_h, s, img_dev, tmp.p, (const int*)pl.bx, (const int*)pl.kx, \
+                                         pl.ksx, rows_total, width, ow, rpb, in_bytes)
+        const int opt = (ow + 255) / 256;
+        if (pl.ksx <= 4) { if (opt <= 1) WM_RH(4, 1); else if (opt <= 2) WM_RH(4, 2); else if (opt <= 3) WM_RH(4, 3); else WM_RH(4, 4); }
+        else if (pl.ksx <= 12) { if (opt <= 1) WM_RH(12, 1); else if (opt <= 2) WM_RH(12, 2); else if (opt <= 3) WM_RH(12, 3); else WM_RH(12, 4); }
+        else { if (opt <= 1) WM_RH(20, 1); else if (opt <= 2) WM_RH(20, 2); else if (opt <= 3) WM_RH(20, 3); else WM_RH(20, 4); }
+#undef WM_RH
+    } else {
+        hipLaunchKernelGGL(resize_h_u8_kernel, dim3(grid_for((int64_t)batch * height * ow)), dim3(256), 0, s, img_dev, tmp.p, (const int*)pl.bx,
+                           (const int*)pl.kx, pl.ksx, batch, height, width, ow);
+    }
+    if (ow % 4 == 0 && !(getenv("WM_RESIZE_GENERIC") && atoi(getenv("WM_RESIZE_GENERIC"))))
+        hipLaunchKernelGGL(resize_v_normalize4_kernel, dim3((unsigned)batch * 1024u), dim3(256), 0, s, (const unsigned char*)tmp.p, out_dev,
+                           (const int*)pl.by, (const int*)pl.ky, pl.ksy, height, ow, oh);
+    else
+        hipLaunchKernelGGL(resize_v_normalize_kernel, dim3(grid_for((int64_t)batch * 1024 * 1024)), dim3(256), 0, s, (const unsigned char*)tmp.p, out_dev,
+                           (const int*)pl.by, (const int*)pl.ky, pl.ksy, batch, height, ow, oh);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2146,6 +2248,12 @@ extern "C" int wm_op_cvt_f32_to_fp8(const float* in_dev, void* out_dev, int64_t 
 extern "C" int wm_op_conv3x3_16(const void* a_dev, const void* w_dev, float* out_dev, int batch, int c_out, int c_in, int precision,
                                void* stream) {
     return launch_conv3x3_16(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, out_dev, batch * 4096, c_out, c_in);
+}
+
+extern "C" int wm_op_patch_embed16(const void* img16_dev, const void* w_dev, const float* bias_dev, float* out_f32_dev, void* out_16_dev,
+                                  int batch, int n_out, int c_in, int precision, void* stream) {
+    if (!img16_dev || !w_dev) return fail("wm_op_patch_embed16: null buffer");
+    return launch_patch_embed16(nullptr, (hipStream_t)stream, precision, img16_dev, w_dev, bias_dev, nullptr, 0, out_f32_dev, out_16_dev, batch, n_out, c_in);
 }
 
 extern "C" int wm_op_gemm32(const float* a_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* out_dev,
