@@ -15,7 +15,9 @@ rows.sort()
 groups = collections.defaultdict(list)
 prev1024 = 0
 for t, name, grid, dur in rows:
-    inst = "FOLDP" if "false, false, true, false" in name else ("FOLDC" if "false, false, false, true" in name else ("LN" if "layernorm" in name or "ln_stats" in name else "plain"))
+    # template tail <..., DBG, FOLDP, FOLDC, SPLIT> (round 4; rounds 2-3 had no SPLIT)
+    inst = ("SPLIT" if "false, true, false, true>" in name else "FOLDP" if "false, true, false, false>" in name else
+            "FOLDC" if "false, false, true, false>" in name else ("LN" if "layernorm" in name or "ln_stats" in name else "plain"))
     key = (inst, grid)
     if grid == 1024 and "gemm16v5" in name and ", 320," in name:
         prev1024 += 1

@@ -9,6 +9,7 @@ mkdir -p gpurun_out/$TAG
 for P in $PRECS; do
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_$P -- python3 bench.py --precision $P --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > gpurun_out/$TAG/prof_${P}_bench.log 2>&1
 cp gpurun_out/prof_${TAG}_$P/*/*kernel_stats.csv gpurun_out/$TAG/${P}_kernel_stats.csv
+python3 tools/gemm_by_shape.py gpurun_out/prof_${TAG}_$P > gpurun_out/$TAG/${P}_gemm_by_shape.txt 2>&1 || true
 echo "stats $P done"
 rocprofv3 -i tools/pmc_traffic.txt --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$P -- python3 bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/$TAG/pmc_$P.log 2>&1
 python3 tools/pmc_summarize.py gpurun_out/pmc_${TAG}_$P gpurun_out/$TAG/${P}_pmc_traffic.json "rocprofv3 -i tools/pmc_traffic.txt --kernel-trace -- python3 bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-roofline" 16 $P > /dev/null
