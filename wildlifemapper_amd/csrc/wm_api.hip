@@ -808,6 +808,9 @@ int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
     const int num_cu = num_cus();
     const int nitems = 25 * a.heads * batch;
     const int grid = nitems < num_cu ? nitems : num_cu;
+    // (round 4: an 8-wave anti-phase form of this kernel -- key tiles of 64 slots in a 4-slot ring filled by LDS-DMA, SIMD partners one
+    // phase apart, ten barriers per item -- was built, is correct and measured 388 vs 274 us per launch: tools/experiments/
+    // attn_win8_antiphase_window.h)
     using L = WindowLds<HD>;
     WM_TRY(set_max_lds((const void*)attn_window_kernel<T16, HD>, L::TOTAL + (WM_DEV_TIMELINE ? 4096 : 0)));
     Bracket br(h, s, WM_KCLASS_ATTN_WIN, 4.0 * batch * a.heads * 4096.0 * 196.0 * HD, 0.0);   // useful work only
