@@ -10,11 +10,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--shapes", default="qkv,proj,lin1,lin2")
 a = ap.parse_args()
 M = a.batch * 4096
 shapes = {"qkv": (M, 3840, 1280, 0, "16"), "proj": (M, 1280, 1280, 0, "f32"), "lin1": (M, 5120, 1280, 1, "8"), "lin2": (M, 1280, 5120, 0, "f32")}
 dev = G.dev()
-for name, (m, n, k, act, mode) in shapes.items():
+for name in a.shapes.split(","):
+    m, n, k, act, mode = shapes[name]
     a8 = G.to_fp8(torch.randn(m, k, device=dev))
     w8, sc = G.quant_weight_fp8(torch.randn(n, k, device=dev) / math.sqrt(k))
     bias = torch.randn(n, device=dev)
