@@ -13,15 +13,15 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
                 rows.append((int(r["Start_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 rows.sort()
 groups = collections.defaultdict(list)
-prev1024 = 0
+prev1024 = collections.Counter()                     # per instance: proj and lin2 alternate inside the blocks' residual instance
 for t, name, grid, dur in rows:
     # template tail <..., DBG, FOLDP, FOLDC, SPLIT> (round 4; rounds 2-3 had no SPLIT)
     inst = ("SPLIT" if "false, true, false, true>" in name else "FOLDP" if "false, true, false, false>" in name else
             "FOLDC" if "false, false, true, false>" in name else ("LN" if "layernorm" in name or "ln_stats" in name else "plain"))
     key = (inst, grid)
     if grid == 1024 and "gemm16v5" in name and ", 320," in name:
-        prev1024 += 1
-        key = (inst, grid, "proj/proj_back/patch" if prev1024 % 2 == 1 else "lin2")
+        prev1024[inst] += 1
+        key = (inst, grid, "proj (or proj_back / patch embed)" if prev1024[inst] % 2 == 1 else "lin2")
     groups[key].append(dur / 1e3)
 for k in sorted(groups, key=str):
     v = groups[k]
