@@ -243,7 +243,8 @@ int wm_profile_read(wm_handle* h, wm_kclass_stat* out /* [WM_KCLASS_COUNT] */);
 #define WM_GEMM_V5_320_SPLIT 15 /* gemm16v5_kernel<320> split-stream producer: residual planes (hi, lo) in and out, row statistics (round 4) */
 #define WM_GEMM_V5_256_SPLIT 16
 #define WM_GEMM_V3_PATCH 17     /* gemm16v3_kernel AMODE 2: implicit-GEMM 16x16 / stride-16 patch embed (round 4) */
-#define WM_GEMM_VARIANT_COUNT 18
+#define WM_GEMM_FP8_256_PLANES 18 /* gemm8_kernel<256> with the stream as planes of rows (hi, lo) in and out (fp8 blocks' proj / lin2, round 4) */
+#define WM_GEMM_VARIANT_COUNT 19
 int wm_debug_gemm_variant_counts(int64_t* out /* [WM_GEMM_VARIANT_COUNT] */, int n);
 int wm_debug_reset_gemm_variant_counts(void);
 
@@ -336,6 +337,20 @@ int wm_op_stream_merge(const void* hi_dev, const void* lo_dev, float* out_dev, i
 int wm_op_gemm8(const void* a_dev, const void* w_dev, const float* wscale_dev, const float* bias_dev,
                 const float* residual_dev, float* out_f32_dev, void* out_16_dev, void* out_8_dev,
                 int M, int N, int K, int act, int precision, void* stream);
+/* The fp8 blocks' residual stream as two 16-bit planes of rows (round 4): hi = round16(x) of type `precision`, lo = fp16(x - hi).
+ * Inside a row each 256-column block is held in the residual epilogue's pass order: column c sits at position
+ * (c & ~255) + ((c >> 5) & 1) * 128 + ((c >> 6) & 3) * 32 + (c & 31).   C % 256 == 0.
+ * wm_op_stream_rows: merge == 0: fp32 x[rows][C] (row-major) -> (hi, lo); merge != 0: (hi, lo) -> x = float(hi) + float(lo).
+ * wm_op_gemm8_planes: (hi, lo) [M,N] += (a w^T) * wscale[n] + bias[n], in place: v = (acc * wscale + bias) + (float(hi) + float(lo)),
+ *   hi' = round16(v), lo' = fp16(v - hi'); shapes as wm_op_gemm8.
+ * wm_op_layernorm_fp8_plane: the blocks' LayerNorm on the hi plane, position-wise: out_8[row][p] = e4m3(LN(x)[column at position p]),
+ *   i.e. e4m3 rows in the SAME column order; the consuming wm_op_gemm8 takes a weight whose K columns are permuted alike.  Mean and
+ *   centred variance over the row (not the column-tiled sums of wm_op_layernorm).  512 <= C <= 1536. */
+int wm_op_stream_rows(float* x_f32_dev, void* hi_dev, void* lo_dev, int64_t rows, int C, int precision, int merge, void* stream);
+int wm_op_gemm8_planes(const void* a_dev, const void* w_dev, const float* wscale_dev, const float* bias_dev, void* hi_dev, void* lo_dev,
+                       int M, int N, int K, int precision, void* stream);
+int wm_op_layernorm_fp8_plane(const void* hi_dev, const float* gamma_dev, const float* beta_dev, float eps, void* out_8_dev, int64_t rows, int C,
+                              int precision, void* stream);
 /* fp32 -> e4m3 bytes, unit scale, round to nearest even, saturating at +-448 (n % 4 == 0) */
 int wm_op_cvt_f32_to_fp8(const float* in_dev, void* out_dev, int64_t n, void* stream);
 

@@ -154,6 +154,54 @@ def stream_merge(hi, lo, prec="fp16"):
     return out
 
 
+def stream_rows_split(x, prec="bf16"):
+    """fp32 rows -> planes of rows (hi of type prec, lo fp16; columns at plane_pos): the fp8 blocks' stream."""
+    code, dt = PRECS[prec]
+    hi = torch.empty(x.shape, device=x.device, dtype=dt)
+    lo = torch.empty(x.shape, device=x.device, dtype=torch.float16)
+    N.check(N.lib().wm_op_stream_rows(N.ptr(x), N.ptr(hi), N.ptr(lo), x.shape[0], x.shape[1], code, 0, sp()))
+    return hi, lo
+
+
+def plane_pos(C, device):
+    """Position of column c inside a row of the fp8 blocks' stream planes (include/wm_hip.h wm_op_stream_rows)."""
+    c = torch.arange(C, device=device)
+    return (c & ~255) + ((c >> 5) & 1) * 128 + ((c >> 6) & 3) * 32 + (c & 31)
+
+
+def stream_rows_merge(hi, lo, prec="bf16"):
+    code, dt = PRECS[prec]
+    out = torch.empty(hi.shape, device=hi.device, dtype=torch.float32)
+    N.check(N.lib().wm_op_stream_rows(N.ptr(out), N.ptr(hi), N.ptr(lo), hi.shape[0], hi.shape[1], code, 1, sp()))
+    return out
+
+
+def gemm8_planes(a8, w8, wscale, bias, hi, lo, prec="bf16"):
+    """(hi, lo) += (a w^T) * wscale + bias on clones."""
+    code, dt = PRECS[prec]
+    M, K = a8.shape
+    hi2, lo2 = hi.clone(), lo.clone()
+    N.check(N.lib().wm_op_gemm8_planes(N.ptr(a8), N.ptr(w8), N.ptr(wscale), N.ptr(bias), N.ptr(hi2), N.ptr(lo2), M, w8.shape[0], K, code, sp()))
+    return hi2, lo2
+
+
+def layernorm_fp8(x, g, b, eps):
+    """The blocks' LayerNorm with e4m3 output (fp32 rows in)."""
+    rows, Cc = x.shape
+    out = torch.empty((rows, Cc), device=x.device, dtype=torch.uint8)
+    N.check(N.lib().wm_op_layernorm(N.ptr(x), N.ptr(g), N.ptr(b), eps, None, N.ptr(out), rows, Cc, N.PREC_FP8, sp()))
+    return out
+
+
+def layernorm_fp8_plane(hi, g, b, eps, prec="bf16"):
+    """e4m3 LayerNorm of the hi plane, output in plane order."""
+    code, dt = PRECS[prec]
+    rows, Cc = hi.shape
+    out = torch.empty((rows, Cc), device=hi.device, dtype=torch.uint8)
+    N.check(N.lib().wm_op_layernorm_fp8_plane(N.ptr(hi), N.ptr(g), N.ptr(b), eps, N.ptr(out), rows, Cc, code, sp()))
+    return out
+
+
 def unpack16(t: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(t)
     N.check(N.lib().wm_op_unpack16(N.ptr(t.contiguous()), N.ptr(out), t.shape[0], t.shape[1], sp()))

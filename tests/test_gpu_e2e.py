@@ -511,7 +511,10 @@ def _fp8_vs_golden(mt, golden_dir, batch):
     var = {k: v for k, v in Nn.gemm_variant_counts().items() if v}
     depth = synth.MODEL_DIMS[mt].depth
     n_bf16 = int(os.environ.get("WM_FP8_BF16_HEAD", 0)) + int(os.environ.get("WM_FP8_BF16_TAIL", 0))
-    assert var.get("fp8_256", 0) == 4 * (depth - n_bf16), var           # qkv, proj, lin1, lin2 of every fp8 block on the fp8 MFMA
+    # qkv, proj, lin1, lin2 of every fp8 block on the fp8 MFMA; proj / lin2 as the instance that keeps the stream as row-major planes
+    rows = int(os.environ.get("WM_FP8_ROWS", 1)) != 0
+    assert var.get("fp8_256", 0) + var.get("fp8_256_planes", 0) == 4 * (depth - n_bf16), var
+    assert var.get("fp8_256_planes", 0) == (2 * (depth - n_bf16) if rows else 0), var
     lg = out["pred_logits"][:n].numpy()
     lerr = np.linalg.norm(lg - fx["pred_logits"]) / np.linalg.norm(fx["pred_logits"])
     berr = np.abs(out["pred_boxes"][:n].numpy() - fx["pred_boxes"]).max()
@@ -566,7 +569,8 @@ def test_fp8_gemm_mask_and_saturation_census(golden_dir):
             torch.cuda.synchronize()
             var = {k: v for k, v in Nn.gemm_variant_counts().items() if v}
             n8 = {"all": 4, "mlp": 2, "qkv+proj": 2}[name] * 12
-            assert var.get("fp8_256", 0) == n8, (name, var)
+            assert var.get("fp8_256", 0) + var.get("fp8_256_planes", 0) == n8, (name, var)
+            assert (var.get("fp8_256_planes", 0) > 0) == (name == "all"), (name, var)   # planes only where all four GEMMs of a block take e4m3
             lg = out["pred_logits"].cpu().numpy()
             errs[name] = float(np.linalg.norm(lg - fx["pred_logits"]) / np.linalg.norm(fx["pred_logits"]))
     finally:

@@ -777,6 +777,57 @@ def test_gemm8_16bit_and_fp8_outputs(M, N, K, act):
     assert G.rel_l2(got, y) < 0.04
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (16384, 1280, 1280), (4096, 1280, 5120), (512, 768, 1280)])
+def test_gemm8_planes_equals_fp32_residual_form(M, N, K, prec):
+    """The fp8 blocks' residual GEMM on row-major planes: the same accumulators and the same fp32 sum as the fp32-residual instance fed
+    float(hi) + float(lo), written back as hi' = round16(v), lo' = fp16(v - hi'): bit for bit."""
+    dev = G.dev()
+    dt = G.PRECS[prec][1]
+    a8 = G.to_fp8(torch.randn(M, K, device=dev))
+    w8, sc = G.quant_weight_fp8(torch.randn(N, K, device=dev) / math.sqrt(K))
+    bias = torch.randn(N, device=dev)
+    x = torch.randn(M, N, device=dev) * 2 + torch.arange(M, device=dev).view(M, 1) % 61 * 0.5
+    hi, lo = G.stream_rows_split(x, prec)
+    pos = G.plane_pos(N, dev)                               # column c of a row sits at pos[c]
+    assert torch.equal(hi[:, pos], x.to(dt)) and torch.equal(lo[:, pos], (x - x.to(dt).float()).to(torch.float16))
+    xr = G.stream_rows_merge(hi, lo, prec)
+    assert torch.equal(xr, hi[:, pos].float() + lo[:, pos].float())
+    assert bool(((xr - x).abs() <= x.abs() * 2.0 ** -19 + 2.0 ** -24).all())
+    (hi2, lo2), var = _variants_run(lambda: G.gemm8_planes(a8, w8, sc, bias, hi, lo, prec))
+    assert var == {"fp8_256_planes": 1}
+    v = G.gemm8(a8, w8, sc, bias, xr, 0, "f32")
+    assert torch.equal(hi2[:, pos], v.to(dt))
+    assert torch.equal(lo2[:, pos], (v - v.to(dt).float()).to(torch.float16))
+
+
+@pytest.mark.parametrize("C", [1280, 1024, 768])
+def test_layernorm_fp8_on_the_hi_plane(C):
+    """LayerNorm to e4m3 read from the 16-bit hi plane and written in plane order: against e4m3 of torch's LayerNorm of float(hi) (same
+    values up to rounding-boundary cases of the 3-bit mantissa) and against the column-tiled fp32-input kernel; and a K-permuted weight
+    undoes the order in the GEMM that consumes it."""
+    dev = G.dev()
+    x = torch.randn(4096, C, device=dev) * 3 + 0.5
+    g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    pos = G.plane_pos(C, dev)
+    for prec in ("bf16", "fp16"):
+        hi, _ = G.stream_rows_split(x, prec)
+        xh = hi[:, pos].float().contiguous()
+        got = G.layernorm_fp8_plane(hi, g, b, 1e-6, prec)[:, pos].contiguous()       # back to column order
+        ref = torch.nn.functional.layer_norm(xh, (C,), g, b, 1e-6)
+        assert (G.from_fp8(got) != G.from_fp8(G.to_fp8(ref))).float().mean().item() < 2e-3
+        assert (got != G.layernorm_fp8(xh, g, b, 1e-6)).float().mean().item() < 2e-3
+        assert G.rel_l2(G.from_fp8(got), ref) < 0.04
+    # the consumer: A in plane order x W with K permuted alike == A in column order x W  (exact products, fp32 sums in another order)
+    w8, sc = G.quant_weight_fp8(torch.randn(256, C, device=dev) / math.sqrt(C))
+    a_plane = G.layernorm_fp8_plane(hi, g, b, 1e-6, prec)
+    wk = torch.empty_like(w8)
+    wk[:, pos] = w8
+    y_plane = G.gemm8(a_plane, wk, sc, None, None, 0, "16", "fp16").float()
+    y_cols = G.gemm8(a_plane[:, pos].contiguous(), w8, sc, None, None, 0, "16", "fp16").float()
+    assert G.rel_l2(y_plane, y_cols) < 1e-3
+
+
 def test_gemm8_rejects_bad_shapes():
     dev = G.dev()
     a8 = torch.zeros(256, 128, device=dev, dtype=torch.uint8)

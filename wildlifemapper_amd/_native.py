@@ -17,7 +17,7 @@ PREC_BY_NAME = {"bf16": PREC_BF16, "fp16": PREC_FP16, "f16": PREC_FP16, "fp8": P
 NUM_QUERIES, NUM_LOGITS = 51, 8
 KCLASS_NAMES = ("gemm16", "attn_window", "attn_global", "layernorm", "other")
 GEMM_VARIANTS = ("v1_128", "v2_160", "v2_128", "v3_lockstep", "v3_conv3x3", "v5_320", "v5_320_res", "v5_256", "v5_256_res",
-                 "v5_320_lnf", "v5_256_lnf", "fp8_320", "fp8_256", "v5_320_foldp", "v5_256_foldp", "v5_320_split", "v5_256_split", "v3_patch_embed")
+                 "v5_320_lnf", "v5_256_lnf", "fp8_320", "fp8_256", "v5_320_foldp", "v5_256_foldp", "v5_320_split", "v5_256_split", "v3_patch_embed", "fp8_256_planes")
 FLAG_CONF, FLAG_SCORE, FLAG_NMS, FLAG_MERGED = 1, 2, 4, 8
 CFG_FUSE_LN = 1
 CFG_FOLD_LN = 2
@@ -87,6 +87,9 @@ SYMBOLS = {
     "wm_op_gemm16_folded": (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P]),
     "wm_op_gemm16_stats": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "wm_op_gemm8": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "wm_op_stream_rows": (_I, [_P, _P, _P, _L, _I, _I, _I, _P]),
+    "wm_op_gemm8_planes": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "wm_op_layernorm_fp8_plane": (_I, [_P, _P, _P, _F, _P, _L, _I, _I, _P]),
     "wm_op_cvt_f32_to_fp8": (_I, [_P, _P, _L, _P]),
     "wm_op_conv3x3_16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "wm_op_patch_embed16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

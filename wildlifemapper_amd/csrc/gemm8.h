@@ -39,6 +39,15 @@ struct Gemm8Args {
     unsigned char* out8;          // [M][N] e4m3 or null
     int M, N, K, act;
     unsigned long long* dbg;      // DBG instance only: [grid][4] stamps
+    // PLANES instance (round 4): the residual stream as two 16-bit planes of rows, hi = T(x), lo = fp16(x - hi) (gemm16_v5.h "Split
+    // stream"; rows here because the only reader of hi is the LayerNorm-to-e4m3 pass): in (res_hi, res_lo), out (out_hi, out_lo),
+    // may alias.  The epilogue moves 8 bytes per element either way; the LayerNorm pass behind it reads 2 instead of 4.
+    // Within a row every 256-column block is stored in the epilogue's PASS order (wm::plane_pos, wm_common.h): a pass reads and
+    // writes one 256-byte run per row and plane (strict row-major gave 64-byte pieces and cost 31 us per launch).
+    const u16* res_hi;
+    const u16* res_lo;
+    u16* out_hi;
+    u16* out_lo;
 };
 
 // BKB = bytes (= fp8 elements) of K per LDS step: 128 (two MFMAs deep, 2 slots of 64 KiB, DMA issued after X_s) or
@@ -57,7 +66,7 @@ constexpr int G8_BM = 256, G8_BN = 256;
 
 // DBG (dev, WM_GEMM8_DBG=1): every workgroup records wall-clock stamps (entry, first barrier passed, loop end, stores
 // acknowledged) into p.dbg; a separate instance, the product kernel carries none of it.
-template <class T, int BKB, bool DBG = false>
+template <class T, int BKB, bool DBG = false, bool PLANES = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(Gemm8Args p) {
     using C = G8<BKB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(Gemm8Args p) {
         return v;
     };
     const int act = p.act & 0xff;
-    if (p.residual != nullptr) {
+    if (PLANES || p.residual != nullptr) {
         // fp32 + residual (proj, lin2): 8 passes (mi, ni) of 64 rows x 128 columns (4 strips of 32, one per wc); the residual
         // strip comes in by LDS-DMA one pass ahead into two landing buffers; then 16-byte chunks along the rows
         constexpr int ROWB = 128 * 4 + 16, STG = 0, L0 = 40 * 1024, L1 = 80 * 1024, LAND = 64 * 128 * 4;
@@ -335,9 +344,19 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(Gemm8Args p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int piece = wave * 4 + i;
+                if constexpr (PLANES) {
+                    // landing image [plane][64 rows][4 strips x 64 B]: pieces 0..15 = hi, 16..31 = lo; a lane's 16 B = 8 columns of one strip.
+                    // The planes keep each 256-column block in PASS order (plane_pos below): the 4 x 32 columns a pass touches are one
+                    // 256-byte run of the row
+                    const int cidx = (piece & 15) * 64 + lane, rr = cidx >> 4, j = cidx & 15;
+                    const int m = m0 + (rr >> 5) * 128 + mi * 32 + (rr & 31);
+                    const u16* src = (piece >> 4 ? p.res_lo : p.res_hi) + (size_t)m * p.N + n0 + 128 * ni + j * 8;
+                    __builtin_amdgcn_global_load_lds((const char*)src, WM_LDS_PTR(dst + piece * 1024), 16, 0, 0);
+                } else {
                 const int rr = piece * 2 + (lane >> 5), ch = lane & 31;
                 const int m = m0 + (rr >> 5) * 128 + mi * 32 + (rr & 31);
                 __builtin_amdgcn_global_load_lds((const char*)(p.residual + (size_t)m * p.N + col_of(ch, ni)), WM_LDS_PTR(dst + piece * 1024), 16, 0, 0);
+                }
             }
         };
         res_dma(0);
@@ -356,7 +375,30 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(Gemm8Args p) {
             for (int it = 0; it < 4; ++it) {
                 const int c = it * 512 + tid, rr = c >> 5, ch = c & 31;
                 const int m = m0 + (rr >> 5) * 128 + mi * 32 + (rr & 31);
-                const f32x4 v = *(const f32x4*)(smem + STG + rr * ROWB + ch * 16) + *(const f32x4*)(land + c * 16);
+                f32x4 res;
+                if constexpr (PLANES) {
+                    const int off = rr * 256 + ch * 8;
+                    const typename T::vec4 h4 = *(const typename T::vec4*)(land + off);
+                    const f16x4 l4 = *(const f16x4*)(land + 16384 + off);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) res[j] = T::to_f32(h4[j]) + (float)l4[j];
+                } else {
+                    res = *(const f32x4*)(land + c * 16);
+                }
+                const f32x4 v = *(const f32x4*)(smem + STG + rr * ROWB + ch * 16) + res;
+                if constexpr (PLANES) {
+                    // (8 columns per thread with 16-byte plane accesses measured 0.7 ms per step slower than this: profiles/r4_dev)
+                    typename T::vec4 o;
+                    f16x4 lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = T::from_f32(v[j]);
+                        lo[j] = FP16::from_f32(v[j] - T::to_f32(o[j]));
+                    }
+                    *(typename T::vec4*)(p.out_hi + (size_t)m * p.N + n0 + 128 * ni + ch * 4) = o;
+                    *(f16x4*)(p.out_lo + (size_t)m * p.N + n0 + 128 * ni + ch * 4) = lo;
+                    continue;
+                }
                 if (p.out32) *(f32x4*)(p.out32 + (size_t)m * p.N + col_of(ch, ni)) = v;
                 if (p.out16) {
                     typename T::vec4 o;

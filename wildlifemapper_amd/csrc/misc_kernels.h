@@ -162,6 +162,90 @@ __global__ __launch_bounds__(256) void layernorm_tiled_kernel(const float* __res
     }
 }
 
+// The fp8 blocks' LayerNorm on the stream's hi plane (gemm8.h PLANES): position-wise.  Input: the hi plane of rows (16-bit type TIN,
+// column c at plane_pos(c)); output: e4m3 rows IN THE SAME ORDER (position p holds LN(x)[plane_col(p)]), consumed by a gemm8 launch whose
+// weight has its K columns permuted alike (wm_api.hip upload8: a dot product does not care).  So the kernel reads and writes whole
+// contiguous runs: a lane owns the 16-byte chunks lane + 64 j of the row (1 KiB per load instruction, 512 B per store instruction;
+// the column-tiled kernel above wrote 64-byte pieces 320 columns apart).  Statistics: mean, then the centred second moment, both over
+// the wave.  One wave per row, NJ = ceil(C / 512) chunks per lane, grid (rows / 4) x 256 threads.
+template <class TIN, int NJ, int RPW>
+__global__ __launch_bounds__(256) void layernorm_plane_fp8_kernel(const u16* __restrict__ hi, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float eps, unsigned char* __restrict__ out, int64_t rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;       // RPW rows per wave, all loads issued before the first use (1 and 2 measured equal: 1)
+    if (row0 >= rows) return;
+    const int nch = C >> 3;
+    uint4 raw[RPW][NJ];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (lane + 64 * j < nch && row0 + r < rows) raw[r][j] = *(const uint4*)(hi + (row0 + r) * C + (lane + 64 * j) * 8);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= rows) break;
+        float v[NJ][8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (lane + 64 * j < nch) {
+                union { uint4 raw; typename TIN::vec4 h[2]; } u;
+                u.raw = raw[r][j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[j][e] = TIN::to_f32(u.h[e >> 2][e & 3]);
+                    s += v[j][e];
+                }
+            }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (lane + 64 * j < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[j][e] -= mean;
+                    q = fmaf(v[j][e], v[j][e], q);
+                }
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int p = lane + 64 * j;
+            if (p < nch) {
+                const int c0 = plane_col(p * 8);              // 8 consecutive positions are 8 consecutive columns
+                uint2 o;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const f32x4 g = *(const f32x4*)(gamma + c0 + 4 * hh);
+                    const f32x4 b = *(const f32x4*)(beta + c0 + 4 * hh);
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = fmaf(v[j][4 * hh + e] * rstd, g[e], b[e]);
+                    (hh ? o.y : o.x) = pack4_e4m3(y);
+                }
+                *(uint2*)(out + row * C + p * 8) = o;
+            }
+        }
+    }
+}
+
+// the stream's planes of rows -> fp16 rows in column order (the neck's operand): out[row][c] = fp16(float(hi) + float(lo))
+template <class T>
+__global__ __launch_bounds__(256) void stream_rows_to_fp16_kernel(const u16* __restrict__ hi, const u16* __restrict__ lo, u16* __restrict__ out, int64_t n4, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i * 4 / C;
+        const int64_t at = row * C + plane_pos((int)(i * 4 - row * C));
+        const typename T::vec4 h4 = *(const typename T::vec4*)(hi + at);
+        const f16x4 l4 = *(const f16x4*)(lo + at);
+        typename FP16::vec4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = FP16::from_f32(T::to_f32(h4[j]) + (float)l4[j]);
+        *(typename FP16::vec4*)(out + i * 4) = o;
+    }
+}
+
 // Folded LayerNorm, weight side (once per wm_finalize_weights): from the weight W [N][K] (row-major), the LayerNorm's
 // gamma / beta [K] and the Linear's bias [N]:
 //   wf[n][k] = round16(gamma[k] * W[n][k])   written in LDS-image order
@@ -278,6 +362,39 @@ __global__ __launch_bounds__(256) void stream_merge_kernel(const u16* __restrict
         }
         *(f32x4*)dst = a;
         *(f32x4*)(dst + 4) = b;
+    }
+}
+
+// Row forms of the split stream (the fp8 blocks: gemm8.h PLANES; column c of a row sits at plane_pos(c)): fp32 rows -> (hi, lo);
+// (hi, lo) -> fp32 rows.  n4 = elements / 4, C % 256 == 0.
+template <class T>
+__global__ __launch_bounds__(256) void stream_split_rows_kernel(const float* __restrict__ x, u16* __restrict__ hi, u16* __restrict__ lo, int64_t n4, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i * 4 / C;
+        const int64_t at = row * C + plane_pos((int)(i * 4 - row * C));
+        const f32x4 v = *(const f32x4*)(x + i * 4);
+        typename T::vec4 o;
+        f16x4 l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = T::from_f32(v[j]);
+            l[j] = FP16::from_f32(v[j] - T::to_f32(o[j]));
+        }
+        *(typename T::vec4*)(hi + at) = o;
+        *(f16x4*)(lo + at) = l;
+    }
+}
+template <class T>
+__global__ __launch_bounds__(256) void stream_merge_rows_kernel(const u16* __restrict__ hi, const u16* __restrict__ lo, float* __restrict__ out, int64_t n4, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i * 4 / C;
+        const int64_t at = row * C + plane_pos((int)(i * 4 - row * C));
+        const typename T::vec4 h4 = *(const typename T::vec4*)(hi + at);
+        const f16x4 l4 = *(const f16x4*)(lo + at);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = T::to_f32(h4[j]) + (float)l4[j];
+        *(f32x4*)(out + i * 4) = v;
     }
 }
 

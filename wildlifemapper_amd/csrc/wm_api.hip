@@ -246,10 +246,14 @@ struct wm_handle {
     // overflow: host-pinned, device-visible word the stream's producers set when an fp16 hi plane clamps (wm_stream_overflow).
     uint16_t* lo16 = nullptr;
     bool split = false;
+    // fp8 blocks (round 4): the stream as two planes of rows (x16last = hi bf16, lo16; gemm8.h PLANES) between the e4m3 residual GEMMs, so the
+    // LayerNorm-to-e4m3 pass reads 2 bytes per element (gemm8.h PLANES); WM_FP8_ROWS=0 keeps the fp32 stream (A/B runs)
+    bool rows8 = true;
     bool fold_from16 = false;               // WM_FOLD_FROM16=1 (A/B runs): gamma (.) W from the 16-bit weight, rounded twice (round 3's form)
     int* overflow = nullptr;
     bool fold = false, fold_bf16 = false;   // WM_CFG_FOLD_LN: fp16-operand blocks; WM_CFG_FOLD_LN_BF16: bf16-operand blocks too
     std::map<std::string, uint16_t*> w16p;  // the same weights in LDS-image order (gemm16_v5.h "Operand layout"), for the 256-row-tile kernels
+    std::map<std::string, uint8_t*> w8k;    // qkv / lin1 of the fp8 blocks again with the K columns at wm::plane_pos (operand = layernorm_plane_fp8_kernel's output)
     std::map<std::string, uint8_t*> w8;     // WM_PREC_FP8: e4m3 weights of the blocks' GEMMs; their per-channel scales live in w32[name + ".wscale"]
     uint8_t* ao8 = nullptr;                 // attention output as e4m3 (A operand of proj)
     std::map<std::string, float*> w32;
@@ -579,13 +583,13 @@ int launch_gemm16(wm_handle* h, hipStream_t s, int prec, const void* A, const vo
 
 // fp8 GEMM (gemm8.h).  prec16 = type of a 16-bit output.  K-step 128 (the 64-byte / 4-slot variant measured equal or
 // 1-3 % slower: tools/experiments/gemm8_bk64.h, profiles/r2_dev/gemm8_bench_b16_bk64.txt).
-template <class T16, int BKB>
+template <class T16, int BKB, bool PLANES = false>
 int launch_gemm8_t(wm_handle* h, hipStream_t s, Gemm8Args a, int grid, double flops, double bytes) {
     using G = G8<BKB>;
 #if WM_DEV_TIMELINE
     static const bool dbg = getenv("WM_GEMM8_DBG") != nullptr;          // dev: per-workgroup wall-clock stamps of the 5th launch
     static int dbg_count = 0;
-    if (dbg && ++dbg_count == 5) {
+    if (!PLANES && dbg && ++dbg_count == 5) {
         unsigned long long* buf = nullptr;
         HIP_TRY(hipMalloc((void**)&buf, (size_t)grid * 32 + 16 + 256));
         HIP_TRY(hipMemset(buf, 0, (size_t)grid * 32 + 16 + 256));
@@ -619,21 +623,31 @@ int launch_gemm8_t(wm_handle* h, hipStream_t s, Gemm8Args a, int grid, double fl
         return 0;
     }
 #endif
-    WM_TRY(set_max_lds((const void*)gemm8_kernel<T16, BKB>, G::LDS));
+    WM_TRY(set_max_lds((const void*)gemm8_kernel<T16, BKB, false, PLANES>, G::LDS));
     Bracket br(h, s, WM_KCLASS_GEMM16, flops, bytes);
-    hipLaunchKernelGGL((gemm8_kernel<T16, BKB>), dim3(grid), dim3(512), G::LDS, s, a);
+    hipLaunchKernelGGL((gemm8_kernel<T16, BKB, false, PLANES>), dim3(grid), dim3(512), G::LDS, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int launch_gemm8(wm_handle* h, hipStream_t s, int prec16, const void* A, const void* W, const float* wscale, const float* bias,
-                 const float* res, float* out32, void* out16, void* out8, int M, int N, int K, int act) {
+                 const float* res, float* out32, void* out16, void* out8, int M, int N, int K, int act, void* hi = nullptr, void* lo = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0 || M % G8_BM || N % G8_BN || K % 128 || K < 256)
         return fail("gemm8: shape M=%d N=%d K=%d must be multiples of %d/%d/128 with K >= 256", M, N, K, G8_BM, G8_BN);
     if (!A || !W || !wscale) return fail("gemm8: null operand");
+    if (hi || lo) {                                         // the stream's row-major planes, updated in place (gemm8.h PLANES)
+        if (!hi || !lo || res || out32 || out16 || out8 || act != ACT_NONE) return fail("gemm8: the plane form takes (hi, lo) and nothing else");
+        Gemm8Args a{(const unsigned char*)A, (const unsigned char*)W, wscale, bias, nullptr, nullptr, nullptr, nullptr, M, N, K, act, nullptr,
+                    (const u16*)hi, (const u16*)lo, (u16*)hi, (u16*)lo};
+        count_variant(WM_GEMM_FP8_256_PLANES);
+        const double flops = 2.0 * M * (double)N * K, bytes = (double)M * K + (double)N * K + 8.0 * M * N;
+        if (prec16 == WM_PREC_FP16) return launch_gemm8_t<FP16, 128, true>(h, s, a, (M / G8_BM) * (N / G8_BN), flops, bytes);
+        return launch_gemm8_t<BF16, 128, true>(h, s, a, (M / G8_BM) * (N / G8_BN), flops, bytes);
+    }
     const int modes = (res != nullptr) + (out8 != nullptr) + (res == nullptr && out8 == nullptr && out16 != nullptr);
     if (modes != 1 || (res && !out32 && !out16) || (!res && out32)) return fail("gemm8: outputs must be (residual + out32 [+ out16]) | out8 | out16");
-    Gemm8Args a{(const unsigned char*)A, (const unsigned char*)W, wscale, bias, res, out32, (u16*)out16, (unsigned char*)out8, M, N, K, act, nullptr};
+    Gemm8Args a{(const unsigned char*)A, (const unsigned char*)W, wscale, bias, res, out32, (u16*)out16, (unsigned char*)out8, M, N, K, act, nullptr,
+                nullptr, nullptr, nullptr, nullptr};
     const int grid = (M / G8_BM) * (N / G8_BN);
     count_variant(WM_GEMM_FP8_256);
     const double flops = 2.0 * M * (double)N * K;
@@ -740,6 +754,19 @@ int launch_layernorm_block(wm_handle* h, hipStream_t s, int prec, const float* x
         if (prec == WM_PREC_FP16) hipLaunchKernelGGL((layernorm_tiled_kernel<FP16, 256>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C, packed);
         else hipLaunchKernelGGL((layernorm_tiled_kernel<BF16, 256>), grid, dim3(256), 0, s, x, g, b, eps, (u16*)out16, rows, C, packed);
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// LayerNorm of the fp8 blocks on the stream's hi plane: plane order in, e4m3 in plane order out (layernorm_plane_fp8_kernel)
+int launch_layernorm_plane8(wm_handle* h, hipStream_t s, int in16, const void* hi, const float* g, const float* b, float eps, void* out8, int64_t rows, int C) {
+    if (C % 256 || C > 1536 || C < 512 || (in16 != WM_PREC_BF16 && in16 != WM_PREC_FP16)) return fail("layernorm (plane): C=%d type %d", C, in16);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    Bracket br(h, s, WM_KCLASS_LAYERNORM, 0.0, (double)rows * C * 3.0);
+#define WM_LNP(TIN, NJ) hipLaunchKernelGGL((layernorm_plane_fp8_kernel<TIN, NJ, 1>), grid, dim3(256), 0, s, (const u16*)hi, g, b, eps, (unsigned char*)out8, rows, C)
+    if (C > 1024) { if (in16 == WM_PREC_FP16) WM_LNP(FP16, 3); else WM_LNP(BF16, 3); }
+    else { if (in16 == WM_PREC_FP16) WM_LNP(FP16, 2); else WM_LNP(BF16, 2); }
+#undef WM_LNP
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1120,6 +1147,16 @@ int upload8(wm_handle* h, const std::string& key, const float* src, size_t rows,
     WM_TRY(dalloc(h, &d, rows * cols));
     HIP_TRY(hipMemcpy(d, q.data(), rows * cols, hipMemcpyHostToDevice));
     h->w8[key] = d;
+    const auto ends = [&](const char* suf) { const size_t n = strlen(suf); return key.size() >= n && key.compare(key.size() - n, n, suf) == 0; };
+    if (cols % 256 == 0 && (ends("attn.qkv.weight") || ends("mlp.lin1.weight"))) {
+        std::vector<uint8_t> qk(rows * cols);
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t c = 0; c < cols; ++c) qk[r * cols + (size_t)plane_pos((int)c)] = q[r * cols + c];
+        uint8_t* dk = nullptr;
+        WM_TRY(dalloc(h, &dk, rows * cols));
+        HIP_TRY(hipMemcpy(dk, qk.data(), rows * cols, hipMemcpyHostToDevice));
+        h->w8k[key] = dk;
+    }
     float* ds = nullptr;
     WM_TRY(dalloc(h, &ds, rows * 4));
     HIP_TRY(hipMemcpy(ds, sc.data(), rows * 4, hipMemcpyHostToDevice));
@@ -1168,6 +1205,7 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     h->fold = (cfg->flags & (WM_CFG_FOLD_LN | WM_CFG_FOLD_LN_BF16)) != 0 && !h->row_major;
     h->fold_bf16 = (cfg->flags & WM_CFG_FOLD_LN_BF16) != 0;
     h->fold_from16 = getenv("WM_FOLD_FROM16") && atoi(getenv("WM_FOLD_FROM16")) != 0;
+    h->rows8 = !(getenv("WM_FP8_ROWS") && atoi(getenv("WM_FP8_ROWS")) == 0);
     h->split = h->fold && !(getenv("WM_STREAM_SPLIT") && atoi(getenv("WM_STREAM_SPLIT")) == 0);
     h->fp8_gemms = cfg->fp8_gemms ? (cfg->fp8_gemms & WM_FP8_ALL) : (getenv("WM_FP8_GEMMS") ? (atoi(getenv("WM_FP8_GEMMS")) & WM_FP8_ALL) : WM_FP8_ALL);
     if (cfg->precision == WM_PREC_FP8 && h->fp8_gemms == 0) { delete h; return fail("wm_create: fp8_gemms selects no GEMM"); }
@@ -1311,6 +1349,8 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
         if (is32 != h->wsrc32.end()) { hipFree(is32->second); for (auto& a : h->allocs) if (a == is32->second) a = nullptr; h->wsrc32.erase(is32); }
         auto i8 = h->w8.find(kv.first);
         if (i8 != h->w8.end()) { hipFree(i8->second); for (auto& a : h->allocs) if (a == i8->second) a = nullptr; h->w8.erase(i8); }
+        auto i8k = h->w8k.find(kv.first);
+        if (i8k != h->w8k.end()) { hipFree(i8k->second); for (auto& a : h->allocs) if (a == i8k->second) a = nullptr; h->w8k.erase(i8k); }
         auto isc = h->w32.find(kv.first + ".wscale");
         if (isc != h->w32.end()) { hipFree(isc->second); for (auto& a : h->allocs) if (a == isc->second) a = nullptr; h->w32.erase(isc); }
     }
@@ -1495,6 +1535,23 @@ int launch_stream_merge(wm_handle* h, hipStream_t s, int prec, const void* hi, c
     return 0;
 }
 
+// the fp8 blocks' stream: fp32 rows <-> planes of rows (hi of type prec, lo fp16; column c at wm::plane_pos(c))
+int launch_stream_rows(wm_handle* h, hipStream_t s, int prec, float* x32, void* hi, void* lo, int64_t rows, int C, bool merge) {
+    if (rows <= 0 || C % 256 || (prec != WM_PREC_FP16 && prec != WM_PREC_BF16)) return fail("stream rows: rows=%lld C=%d precision %d", (long long)rows, C, prec);
+    const int64_t n = rows * C;
+    Bracket br(h, s, WM_KCLASS_OTHER, 0.0, (double)n * 8.0);
+    const dim3 grid(grid_for(n / 4));
+    if (merge) {
+        if (prec == WM_PREC_FP16) hipLaunchKernelGGL(stream_merge_rows_kernel<FP16>, grid, dim3(256), 0, s, (const u16*)hi, (const u16*)lo, x32, n / 4, C);
+        else hipLaunchKernelGGL(stream_merge_rows_kernel<BF16>, grid, dim3(256), 0, s, (const u16*)hi, (const u16*)lo, x32, n / 4, C);
+    } else {
+        if (prec == WM_PREC_FP16) hipLaunchKernelGGL(stream_split_rows_kernel<FP16>, grid, dim3(256), 0, s, (const float*)x32, (u16*)hi, (u16*)lo, n / 4, C);
+        else hipLaunchKernelGGL(stream_split_rows_kernel<BF16>, grid, dim3(256), 0, s, (const float*)x32, (u16*)hi, (u16*)lo, n / 4, C);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // opt-in census of clamped values in a 16-bit / e4m3 activation buffer (wm_debug_saturation_enable); prec = element type
 int sat_check(wm_handle* h, hipStream_t s, int which, const void* buf, int64_t n_elems, int prec) {
     if (!h->sat_on) return 0;
@@ -1563,11 +1620,13 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     // a call whose residual GEMMs run the 256-row-tile kernel (4+ tiles for ViT-H); a smaller call keeps fp32 and rounds the stream
     // to hi + lo in ln_stats_x16_kernel, so both forms carry the same values bit for bit (gemm16_v5.h "Split stream").
     const bool split_call = h->split && gemm16_takes_v5(M, D, D) && gemm16_takes_v5(M, D, 4 * D);
-    bool st_split = false;
+    // st_rows (fp8 blocks): as two planes of rows (x16last = hi bf16, lo16; columns at plane_pos), `resid` stale (gemm8.h PLANES).
+    bool st_split = false, st_rows = false;
     int raw_prec = -1;
     auto to_fp32 = [&]() -> int {                           // planes -> resid (type boundaries, non-folded blocks, the bf16 neck input)
         if (st_split) WM_TRY(launch_stream_merge(h, s, raw_prec, h->xn16, h->lo16, h->resid, M, D));
-        st_split = false;
+        if (st_rows) WM_TRY(launch_stream_rows(h, s, WM_PREC_BF16, h->resid, h->x16last, h->lo16, M, D, true));
+        st_split = st_rows = false;
         return 0;
     };
     auto planes_from_fp32 = [&](int P) -> int {             // resid -> statistics + planes of type P (resid rounded in place unless the call is split)
@@ -1579,8 +1638,9 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     };
     auto tap = [&](int which) -> int {
         if (h->tap_which != which) return 0;
-        if (!st_split) return do_tap(h, s, which, B);
+        if (!st_split && !st_rows) return do_tap(h, s, which, B);
         WM_TRY(tap_alloc(h));
+        if (st_rows) return launch_stream_rows(h, s, WM_PREC_BF16, h->tap_buf, h->x16last, h->lo16, M, D, true);
         return launch_stream_merge(h, s, raw_prec, h->xn16, h->lo16, h->tap_buf, M, D);
     };
     // a residual GEMM of a folded block of type P: x += A W^T + b, leaving the stream with planes + statistics of type P
@@ -1656,13 +1716,23 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
             WM_TRY(tap(i));
             continue;
         }
-        WM_TRY(to_fp32());
+        // a block whose four GEMMs take e4m3 keeps the stream as planes of rows: proj / lin2 move the same 8 bytes per element, the
+        // two LayerNorm passes read the 2-byte hi plane instead of 4-byte rows (their e4m3 output has a 2^-4 step; hi is bf16, 2^-9)
+        const bool rows_blk = h->rows8 && q8 && p8 && m8 && D % 256 == 0 && D >= 512 && D <= 1536 && h->w8k.count(b + "attn.qkv.weight") && h->w8k.count(b + "mlp.lin1.weight");
+        if (rows_blk && !st_rows) {
+            WM_TRY(to_fp32());
+            WM_TRY(launch_stream_rows(h, s, P, h->resid, h->x16last, h->lo16, M, D, false));
+            st_rows = true;
+        } else if (!rows_blk) {
+            WM_TRY(to_fp32());
+        }
         raw_prec = -1;
-        WM_TRY(launch_layernorm_block(h, s, q8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D, pk_qkv));
+        if (st_rows) WM_TRY(launch_layernorm_plane8(h, s, P, h->x16last, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D));
+        else WM_TRY(launch_layernorm_block(h, s, q8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm1.weight"), W32(h, b + "norm1.bias"), 1e-6f, h->xn16, M, D, pk_qkv));
         xn_packed = pk_qkv;
         WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, q8 ? WM_PREC_FP8 : P));
         if (q8)
-            WM_TRY(launch_gemm8(h, s, P, h->xn16, W8(b + "attn.qkv.weight"), W32(h, b + "attn.qkv.weight.wscale"), W32(h, b + "attn.qkv.bias"),
+            WM_TRY(launch_gemm8(h, s, P, h->xn16, st_rows ? h->w8k.at(b + "attn.qkv.weight") : W8(b + "attn.qkv.weight"), W32(h, b + "attn.qkv.weight.wscale"), W32(h, b + "attn.qkv.bias"),
                                 nullptr, nullptr, h->qkv16, nullptr, M, 3 * D, D, ACT_NONE));
         else
             WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "attn.qkv.weight"), W32(h, b + "attn.qkv.bias"), nullptr, 0, nullptr,
@@ -1673,22 +1743,30 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
                                         W32(h, b + "attn.rel_pos_w"), h->ao16, B, h->heads, h->hd, h->is_global[i] ? 0 : 14, p8 ? h->ao8 : nullptr, nullptr, nullptr, 0, 1));
         if (p8) WM_TRY(sat_check(h, s, WM_SAT_ATTN, h->ao8, (int64_t)M * D, WM_PREC_FP8));
         else WM_TRY(sat_check(h, s, WM_SAT_ATTN, h->ao16, (int64_t)M * D, P));
-        if (p8) {
+        if (st_rows) {
+            WM_TRY(launch_gemm8(h, s, P, h->ao8, W8(b + "attn.proj.weight"), W32(h, b + "attn.proj.weight.wscale"), W32(h, b + "attn.proj.bias"),
+                                nullptr, nullptr, nullptr, nullptr, M, D, D, ACT_NONE, h->x16last, h->lo16));
+        } else if (p8) {
             WM_TRY(launch_gemm8(h, s, P, h->ao8, W8(b + "attn.proj.weight"), W32(h, b + "attn.proj.weight.wscale"), W32(h, b + "attn.proj.bias"),
                                 h->resid, h->resid, nullptr, nullptr, M, D, D, ACT_NONE));
         } else {
             WM_TRY(launch_gemm16(h, s, P, h->ao16, W16(h, b + "attn.proj.weight"), W32(h, b + "attn.proj.bias"), h->resid, 0,
                                  h->resid, nullptr, M, D, D, ACT_NONE, GX(W16P(h, b + "attn.proj.weight"))));
         }
-        WM_TRY(launch_layernorm_block(h, s, m8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D, pk_lin1));
+        if (st_rows) WM_TRY(launch_layernorm_plane8(h, s, P, h->x16last, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D));
+        else WM_TRY(launch_layernorm_block(h, s, m8 ? WM_PREC_FP8 : P, h->resid, W32(h, b + "norm2.weight"), W32(h, b + "norm2.bias"), 1e-6f, h->xn16, M, D, pk_lin1));
         xn_packed = pk_lin1;
         WM_TRY(sat_check(h, s, WM_SAT_LN, h->xn16, (int64_t)M * D, m8 ? WM_PREC_FP8 : P));
         if (m8) {
-            WM_TRY(launch_gemm8(h, s, P, h->xn16, W8(b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.weight.wscale"), W32(h, b + "mlp.lin1.bias"),
+            WM_TRY(launch_gemm8(h, s, P, h->xn16, st_rows ? h->w8k.at(b + "mlp.lin1.weight") : W8(b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.weight.wscale"), W32(h, b + "mlp.lin1.bias"),
                                 nullptr, nullptr, nullptr, h->hid16, M, 4 * D, D, ACT_GELU));
             WM_TRY(sat_check(h, s, WM_SAT_HID, h->hid16, (int64_t)M * 4 * D, WM_PREC_FP8));
-            WM_TRY(launch_gemm8(h, s, P, h->hid16, W8(b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.weight.wscale"), W32(h, b + "mlp.lin2.bias"),
-                                h->resid, h->resid, nullptr, nullptr, M, D, 4 * D, ACT_NONE));
+            if (st_rows)
+                WM_TRY(launch_gemm8(h, s, P, h->hid16, W8(b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.weight.wscale"), W32(h, b + "mlp.lin2.bias"),
+                                    nullptr, nullptr, nullptr, nullptr, M, D, 4 * D, ACT_NONE, h->x16last, h->lo16));
+            else
+                WM_TRY(launch_gemm8(h, s, P, h->hid16, W8(b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.weight.wscale"), W32(h, b + "mlp.lin2.bias"),
+                                    h->resid, h->resid, nullptr, nullptr, M, D, 4 * D, ACT_NONE));
         } else {
             WM_TRY(launch_gemm16(h, s, P, h->xn16, W16(h, b + "mlp.lin1.weight"), W32(h, b + "mlp.lin1.bias"), nullptr, 0, nullptr,
                                  h->hid16, M, 4 * D, D, ACT_GELU, GX(W16P(h, b + "mlp.lin1.weight"), xn_packed, pk_lin2)));
@@ -1696,7 +1774,7 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
             WM_TRY(launch_gemm16(h, s, P, h->hid16, W16(h, b + "mlp.lin2.weight"), W32(h, b + "mlp.lin2.bias"), h->resid, 0,
                                  h->resid, nullptr, M, D, 4 * D, ACT_NONE, GX(W16P(h, b + "mlp.lin2.weight"), pk_lin2)));
         }
-        WM_TRY(do_tap(h, s, i, B));
+        WM_TRY(tap(i));
     }
 
     // ---- neck (image_encoder.py:105-121,136) ----
@@ -1707,6 +1785,11 @@ int encoder_impl(wm_handle* h, const float* x, const float* hfc, float* out_nchw
     if (h->split && raw_prec == PS) {
         if (gemm16_takes_v5(M, OUTC, D)) { neck_a = h->xn16; neck_packed = 1; }
         else WM_TRY(launch_simple(h, s, B * 21.0e6, unpack16_lds_image_kernel, dim3(grid_for((int64_t)M * D / 8)), dim3(256), (const uint4*)h->xn16, (uint4*)h->x16last, (int64_t)M, D));
+    } else if (st_rows) {                                   // the fp8 blocks' planes: one pass to fp16 rows (hid16 is free after the last block)
+        neck_a = h->hid16;
+        WM_TRY(launch_simple(h, s, B * 31.5e6, stream_rows_to_fp16_kernel<BF16>, dim3(grid_for((int64_t)M * D / 4)), dim3(256), (const u16*)h->x16last, (const u16*)h->lo16,
+                             (u16*)h->hid16, (int64_t)M * D / 4, D));
+        st_rows = false;
     } else {
         WM_TRY(to_fp32());
         WM_TRY(launch_simple(h, s, B * 31.5e6, cvt_f32_to_16_kernel<FP16>, dim3(grid_for((int64_t)M * D / 4)), dim3(256), (const float*)h->resid, (u16*)h->x16last, (int64_t)M * D / 4));
@@ -2239,6 +2322,24 @@ extern "C" int wm_op_gemm8(const void* a_dev, const void* w_dev, const float* ws
                            float* out_f32_dev, void* out_16_dev, void* out_8_dev, int M, int N, int K, int act, int precision, void* stream) {
     return launch_gemm8(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, wscale_dev, bias_dev, residual_dev, out_f32_dev, out_16_dev, out_8_dev,
                         M, N, K, act);
+}
+
+extern "C" int wm_op_gemm8_planes(const void* a_dev, const void* w_dev, const float* wscale_dev, const float* bias_dev, void* hi_dev, void* lo_dev,
+                                  int M, int N, int K, int precision, void* stream) {
+    if (!hi_dev || !lo_dev) return fail("wm_op_gemm8_planes: null plane");
+    return launch_gemm8(nullptr, (hipStream_t)stream, precision, a_dev, w_dev, wscale_dev, bias_dev, nullptr, nullptr, nullptr, nullptr, M, N, K, ACT_NONE,
+                        hi_dev, lo_dev);
+}
+
+extern "C" int wm_op_stream_rows(float* x_f32_dev, void* hi_dev, void* lo_dev, int64_t rows, int C, int precision, int merge, void* stream) {
+    if (!x_f32_dev || !hi_dev || !lo_dev) return fail("wm_op_stream_rows: null buffer");
+    return launch_stream_rows(nullptr, (hipStream_t)stream, precision, x_f32_dev, hi_dev, lo_dev, rows, C, merge != 0);
+}
+
+extern "C" int wm_op_layernorm_fp8_plane(const void* hi_dev, const float* gamma_dev, const float* beta_dev, float eps, void* out_8_dev, int64_t rows, int C,
+                                        int precision, void* stream) {
+    if (!hi_dev || !out_8_dev || !gamma_dev || !beta_dev) return fail("wm_op_layernorm_fp8_plane: null buffer");
+    return launch_layernorm_plane8(nullptr, (hipStream_t)stream, precision, hi_dev, gamma_dev, beta_dev, eps, out_8_dev, rows, C);
 }
 
 extern "C" int wm_op_cvt_f32_to_fp8(const float* in_dev, void* out_dev, int64_t n, void* stream) {

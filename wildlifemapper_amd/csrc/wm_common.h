@@ -77,6 +77,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Column -> position inside a row of the fp8 blocks' stream planes (gemm8.h PLANES): each 256-column block holds its columns in the
+// order the residual epilogue's passes touch them, [half ni][strip][32]: col = 64 strip + 32 ni + c  ->  pos = 128 ni + 32 strip + c.
+// A bijection on aligned groups of 32 columns; col must be a multiple of 4 for the vector accesses that use it.
+__host__ __device__ __forceinline__ int plane_pos(int col) {
+    const int b = col & 255;
+    return (col & ~255) + ((b >> 5) & 1) * 128 + (b >> 6) * 32 + (b & 31);
+}
+__host__ __device__ __forceinline__ int plane_col(int pos) {      // the inverse
+    const int b = pos & 255;
+    return (pos & ~255) + ((b >> 5) & 3) * 64 + (b >> 7) * 32 + (b & 31);
+}
+
 // exact-erf GELU of common.py:26 (nn.GELU default).  Two forms:
 //   gelu_erf       - libm erff, used where the result stays fp32 (gemm32);
 //   gelu_erf_fast  - erf(x / sqrt 2) as a clamped rational x P(x^2) / Q(x^2), degree 3/3 in x^2, |x| clamped to
