@@ -126,6 +126,12 @@ def gelu_erf(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
+def gelu_logistic(x: Tensor) -> Tensor:
+    """The fp8 emulation's GELU (cfg.block_fp8 only; NOT the reference's): x / (1 + 2^(-x (a + b x^2))), the form gemm8.h's e4m3
+    epilogue evaluates (wm_common.h gelu_e4m3_fast2; within 2.7e-4 of gelu_erf everywhere, far below an e4m3 step)."""
+    return x / (1.0 + torch.exp2(-x * (2.3087653 + 0.10012561 * x * x)))
+
+
 # ----------------------------------------------------------------------------
 # A2  MedSAM.fft  (network.py:36-57)
 # ----------------------------------------------------------------------------
@@ -300,7 +306,8 @@ def encoder_block(x: Tensor, W: Dict[str, Tensor], i: int, cfg: OracleCfg) -> Te
         y = from_windows(yw, cfg.window, n, x.shape[1])
     x = x + y
     z = layer_norm(x, W[pre + "norm2.weight"], W[pre + "norm2.bias"], 1e-6)
-    z = gelu_erf(block_linear(z, W[pre + "mlp.lin1.weight"], W[pre + "mlp.lin1.bias"], cfg))
+    z = block_linear(z, W[pre + "mlp.lin1.weight"], W[pre + "mlp.lin1.bias"], cfg)
+    z = gelu_logistic(z) if cfg.block_fp8 else gelu_erf(z)
     z = block_linear(z, W[pre + "mlp.lin2.weight"], W[pre + "mlp.lin2.bias"], cfg)
     return x + z
 

@@ -770,8 +770,11 @@ def test_gemm8_16bit_and_fp8_outputs(M, N, K, act):
     assert G.rel_l2(o16.float(), y) < OUT16_TOL["bf16"]
     o8 = G.gemm8(a8, w8, sc, bias, None, act, "8")
     got = G.from_fp8(o8)
-    # e4m3 output: one rounding to 3 mantissa bits (relative 2^-4 worst case, 0.036 rms) of the fp32 value
-    want8 = G.from_fp8(G.to_fp8(y))
+    # e4m3 output: one rounding to 3 mantissa bits (relative 2^-4 worst case, 0.036 rms) of the fp32 value.  Its GELU is the
+    # logistic form (wm_common.h gelu_e4m3_fast2: within 2.7e-4 of the erf form, 1.8 % of the e4m3 outputs one step away): the
+    # bits are checked against that form, the distance against the exact one
+    y8 = O.gelu_logistic((G.from_fp8(a8) @ G.from_fp8(w8).t()) * sc + bias) if act == 1 else y
+    want8 = G.from_fp8(G.to_fp8(y8))
     mism = (got != want8).float().mean().item()
     assert mism < 2e-3, mism                              # ties / fp32 summation-order differences at rounding boundaries only
     assert G.rel_l2(got, y) < 0.04

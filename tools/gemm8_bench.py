@@ -13,7 +13,7 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--shapes", default="qkv,proj,lin1,lin2")
 a = ap.parse_args()
 M = a.batch * 4096
-shapes = {"qkv": (M, 3840, 1280, 0, "16"), "proj": (M, 1280, 1280, 0, "f32"), "lin1": (M, 5120, 1280, 1, "8"), "lin2": (M, 1280, 5120, 0, "f32")}
+shapes = {"qkv": (M, 3840, 1280, 0, "16"), "proj": (M, 1280, 1280, 0, "f32"), "lin1": (M, 5120, 1280, 1, "8"), "lin1_noact": (M, 5120, 1280, 0, "8"), "lin2": (M, 1280, 5120, 0, "f32")}
 dev = G.dev()
 for name in a.shapes.split(","):
     m, n, k, act, mode = shapes[name]

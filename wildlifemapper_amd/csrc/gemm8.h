@@ -23,6 +23,10 @@
 #include "gemm16_v5.h"
 #include "misc_kernels.h"
 
+#ifndef WM_GEMM8_GELU
+#define WM_GEMM8_GELU gelu_e4m3_fast4      // dev A/B: -DWM_GEMM8_GELU=gelu_erf_fast4
+#endif
+
 namespace wm {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(Gemm8Args p) {
 #pragma unroll
                 for (int mi = 0; mi < C::MT; ++mi) {
                     f32x4 v = scaled(mi, ni, g, scv[ni][g], biv[ni][g]);
-                    if (act == ACT_GELU) v = gelu_erf_fast4(v);
+                    if (act == ACT_GELU) v = WM_GEMM8_GELU(v);       // e4m3 output: the 3-bit-mantissa-grade form (wm_common.h)
                     else if (act == ACT_RELU) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
