@@ -16,7 +16,7 @@ python3 tools/pmc_summarize.py gpurun_out/pmc_${TAG}_$P gpurun_out/$TAG/${P}_pmc
 echo "pmc traffic $P done"
 rocprofv3 -i tools/pmc_util.txt --kernel-trace --output-format csv -d gpurun_out/pmcu_${TAG}_$P -- python3 bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/$TAG/pmcu_$P.log 2>&1
 # all 16-bit GEMM launches, then per instance: FOLDC (qkv, lin1), SPLIT (proj, lin2); the attention kernels; what is left of the LayerNorm
-python3 tools/pmc_kernel.py gpurun_out/pmcu_${TAG}_$P gemm16v5_kernel "3, false, false, true, false>" "3, false, true, false, true>" gemm8_kernel attn_window_kernel attn_global8_kernel attn_global_kernel layernorm_tiled ln_stats_x16 > gpurun_out/$TAG/${P}_pmc_util.txt
+python3 tools/pmc_kernel.py gpurun_out/pmcu_${TAG}_$P gemm16v5_kernel "3, false, false, true, false>" "3, false, true, false, true>" gemm8_kernel attn_window_kernel attn_global8_kernel attn_global_kernel layernorm_tiled layernorm_plane_fp8 ln_stats_x16 > gpurun_out/$TAG/${P}_pmc_util.txt
 echo "pmc util $P done"
 rm -rf gpurun_out/prof_${TAG}_$P gpurun_out/pmc_${TAG}_$P gpurun_out/pmcu_${TAG}_$P
 done
