@@ -366,7 +366,10 @@ int wm_op_conv3x3_16(const void* a_dev, const void* w_dev, float* out_dev, int b
 int wm_op_patch_embed16(const void* img16_dev, const void* w_dev, const float* bias_dev, float* out_f32_dev, void* out_16_dev,
                         int batch, int n_out, int c_in, int precision, void* stream);
 
-/* fp32 GEMM on the fp32-input MFMA, same contract (act 3 = sigmoid). */
+/* fp32 GEMM, fp32 in and out, same contract (act 3 = sigmoid): on the fp32-input MFMA, or with act | WM_GEMM32_SPLIT in the form the
+ * decoder runs since round 4: every operand value split into two fp16 numbers (hi + lo = x to 2^-22), three 16-bit MFMAs per product
+ * (the lo x lo term dropped), fp32 accumulate: rel-L2 3e-7 against float64 (the fp32 MFMA: 1e-7).  K % 32 == 0 for that form. */
+#define WM_GEMM32_SPLIT 0x100
 int wm_op_gemm32(const float* a_dev, const float* w_dev, const float* bias_dev,
                  const float* residual_dev, float* out_dev, int M, int N, int K, int act, void* stream);
 

@@ -219,11 +219,12 @@ def patch_embed16(img16, w16, bias, prec="fp16", want32=True):
     return o32, o16
 
 
-def gemm32(a, w, bias=None, residual=None, act=0):
+def gemm32(a, w, bias=None, residual=None, act=0, split=False):
+    """split: the fp16-split form on the 16-bit matrix pipe (gemm32.h gemm32x3_kernel), else the fp32 MFMA."""
     M, K = a.shape
     Nn = w.shape[0]
     out = torch.empty((M, Nn), device=a.device, dtype=torch.float32)
-    N.check(N.lib().wm_op_gemm32(N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(residual), N.ptr(out), M, Nn, K, act, sp()))
+    N.check(N.lib().wm_op_gemm32(N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(residual), N.ptr(out), M, Nn, K, act | (N.GEMM32_SPLIT if split else 0), sp()))
     return out
 
 

@@ -492,6 +492,41 @@ def test_gemm32(M, N, K, act):
     assert G.rel_l2(out, y) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,act", [(51, 8, 256, 0), (102, 4, 256, 3), (4096, 128, 256, 0), (51, 2048, 256, 2), (153, 256, 2048, 0),
+                                       (816, 256, 256, 0), (65536, 128, 256, 0), (65536, 256, 128, 0), (64, 64, 32, 1), (70, 14, 96, 0)])
+def test_gemm32_split_form(M, N, K, act):
+    """The decoder's GEMMs since round 4: fp32 in and out on the 16-bit matrix pipe, every operand value split into fp16 hi + lo
+    (gemm32.h gemm32x3_kernel).  Same bound against float64 as the fp32-MFMA kernel; decoder-sized weights (|w| ~ 0.02) and
+    activations spanning 1e-3 .. 30; ragged M and N; one value per operand that needs the lo part to survive at all."""
+    dev = G.dev()
+    a = torch.randn(M, K, device=dev) * torch.exp(torch.randn(M, 1, device=dev) * 1.5)         # rows of very different size
+    w = torch.randn(N, K, device=dev) * 0.02
+    a[0, 0], w[0, 0] = 1.0 + 2.0 ** -12, 1.0 - 2.0 ** -13                                    # not representable in fp16
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(M, N, device=dev)
+    out = G.gemm32(a, w, bias, res, act, split=True)
+    y = (a.double() @ w.double().t() + bias.double())
+    y = {0: y, 1: 0.5 * y * (1 + torch.erf(y / math.sqrt(2))), 2: torch.relu(y), 3: torch.sigmoid(y)}[act] + res.double()
+    assert G.rel_l2(out, y) < 2e-6
+    ref32 = G.gemm32(a, w, bias, res, act)
+    print(f"gemm32 split form M={M} N={N} K={K}: rel-L2 vs float64 {G.rel_l2(out, y):.2e} (fp32 MFMA kernel: {G.rel_l2(ref32, y):.2e})")
+    # per-row error relative to the row's own scale (a small row must not inherit a large row's error)
+    rowerr = ((out.double() - y).norm(dim=1) / (y - res.double()).norm(dim=1).clamp_min(1e-30)).max().item()
+    assert rowerr < 1e-5, rowerr
+
+
+def test_gemm32_split_form_flags_fp16_range():
+    """|a| >= 65504 cannot be split into fp16 parts: the handle-less op has no overflow word to raise, so the result is inf / nan,
+    never a silently clamped number."""
+    dev = G.dev()
+    a = torch.ones(64, 32, device=dev)
+    a[3, 5] = 1e5
+    w = torch.ones(64, 32, device=dev) * 0.01
+    out = G.gemm32(a, w, None, None, 0, split=True)
+    assert not torch.isfinite(out[3]).all()
+    assert torch.isfinite(out[4]).all()
+
+
 @pytest.mark.parametrize("C,eps", [(256, 1e-5), (768, 1e-6), (1024, 1e-5), (1280, 1e-6)])
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 def test_layernorm(C, eps, prec):

@@ -25,6 +25,7 @@ CFG_FOLD_LN_BF16 = 4
 ABI_VERSION = 4            # include/wm_hip.h WM_ABI_VERSION this binding was written for
 FP8_QKV, FP8_PROJ, FP8_MLP, FP8_ALL = 1, 2, 4, 7
 GEMM_W_PACKED, GEMM_A_PACKED, GEMM_OUT_PACKED, LAYOUT_PACKED = 0x1000, 0x2000, 0x4000, 0x100
+GEMM32_SPLIT = 0x100          # wm_op_gemm32: act | GEMM32_SPLIT = the fp16-split form the decoder runs
 SAT_NAMES = ("layernorm_out", "qkv", "attention_out", "mlp_hidden", "last_block_16")
 
 

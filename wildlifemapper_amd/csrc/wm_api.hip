@@ -259,6 +259,7 @@ struct wm_handle {
     std::map<std::string, float*> w32;
     std::vector<void*> allocs;
     Profiler prof;
+    std::map<const float*, std::pair<uint16_t*, uint16_t*>> w32x3;   // decoder weights as fp16 (hi, lo) planes of W * 2^6 (gemm32.h gemm32x3_kernel), by fp32 copy
     std::map<std::pair<const float*, int>, uint16_t*> bias16;   // qkv biases rounded to a 16-bit operand type (window attention's padded tokens), by (fp32 copy, type)
     float* mha_part = nullptr;              // token -> image attention: per key chunk partial softmaxes (launch_mha32)
     size_t mha_part_cap = 0;
@@ -700,9 +701,38 @@ int launch_patch_embed16(wm_handle* h, hipStream_t s, int prec, const void* img1
     return 0;
 }
 
+unsigned grid_for(int64_t n, int per = 256, unsigned cap = 256 * 16);
+
+// fp32 GEMM (the decoder).  mode: 0 = the engine's choice (the fp16-split form on the 16-bit matrix pipe, gemm32.h gemm32x3_kernel,
+// where K % 32 == 0, with W pre-split once per weight upload; WM_GEMM32_F32=1 keeps the fp32-MFMA kernel: A/B runs), 1 = the fp32-MFMA
+// kernel, 2 = the split form with W split per K-step (op-level entry: no handle to cache planes in)
 int launch_gemm32(wm_handle* h, hipStream_t s, const float* A, const float* W, const float* bias, const float* res,
-                  float* out, int M, int N, int K, int act, int lda = 0) {
+                  float* out, int M, int N, int K, int act, int lda = 0, int mode = 0) {
     if (K % 16) return fail("gemm32: K=%d must be a multiple of 16", K);
+    static const bool f32_only = getenv("WM_GEMM32_F32") && atoi(getenv("WM_GEMM32_F32")) != 0;
+    if (mode == 2 && K % 32) return fail("gemm32 (split form): K=%d must be a multiple of 32", K);
+    if (mode == 2 || (mode == 0 && h && !f32_only && K % 32 == 0)) {
+        Gemm32x3Args a{A, W, nullptr, nullptr, bias, res, out, M, N, K, act, lda > 0 ? lda : K, h ? h->overflow : nullptr};
+        if (mode == 0) {                                    // the weight's fp16 planes: made at first use, dropped with the weights
+            auto it = h->w32x3.find(W);
+            if (it == h->w32x3.end()) {
+                uint16_t *hi = nullptr, *lo = nullptr;
+                const size_t n = (size_t)N * K;
+                if (n % 4) return fail("gemm32: weight of %zu elements", n);
+                WM_TRY(dalloc(h, &hi, n * 2)); WM_TRY(dalloc(h, &lo, n * 2));
+                hipLaunchKernelGGL(split_w32_kernel, dim3(grid_for((int64_t)n / 4)), dim3(256), 0, s, W, (u16*)hi, (u16*)lo, (int64_t)n / 4, h->overflow);
+                HIP_TRY(hipGetLastError());
+                it = h->w32x3.emplace(W, std::make_pair(hi, lo)).first;
+            }
+            a.Whi = (const u16*)it->second.first; a.Wlo = (const u16*)it->second.second;
+        }
+        Bracket br(h, s, WM_KCLASS_OTHER, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)M * N) + (mode == 0 ? 4.0 : 4.0) * (double)N * K);
+        const dim3 grid(((N + 63) / 64) * ((M + 63) / 64));
+        if (mode == 0) hipLaunchKernelGGL(gemm32x3_kernel<true>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(gemm32x3_kernel<false>, grid, dim3(256), 0, s, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     Gemm32Args a{A, W, bias, res, out, M, N, K, act, lda > 0 ? lda : K};
     Bracket br(h, s, WM_KCLASS_OTHER, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     hipLaunchKernelGGL(gemm32_kernel, dim3(((N + 63) / 64) * ((M + 63) / 64)), dim3(256), 0, s, a);
@@ -869,7 +899,6 @@ int launch_attn_window_t(wm_handle* h, hipStream_t s, const AttnArgs& a, int bat
     return 0;
 }
 
-unsigned grid_for(int64_t n, int per = 256, unsigned cap = 256 * 16);
 
 // The attention kernels take q in the log2 domain, c1 q with c1 = head_dim^-0.5 * log2 e (attn16.h "Scores").  A caller that holds the
 // reference's plain q (the single-op entry points) gets a scaled copy in a scratch buffer: a.q / a.q_stride are redirected to it.
@@ -1357,6 +1386,9 @@ extern "C" int wm_finalize_weights(wm_handle* h) {
     // 16-bit copies of the qkv biases are keyed by the fp32 copy's address: a re-upload may reuse an address for new values
     for (auto& kv : h->bias16) { hipFree(kv.second); for (auto& a : h->allocs) if (a == kv.second) a = nullptr; }
     h->bias16.clear();
+    for (auto& kv : h->w32x3)
+        for (uint16_t* q : {kv.second.first, kv.second.second}) { hipFree(q); for (auto& a : h->allocs) if (a == q) a = nullptr; }
+    h->w32x3.clear();
     const int D = h->D;
     for (auto& kv : h->staged) {
         const std::string& name = kv.first;
@@ -2362,7 +2394,9 @@ extern "C" int wm_op_patch_embed16(const void* img16_dev, const void* w_dev, con
 
 extern "C" int wm_op_gemm32(const float* a_dev, const float* w_dev, const float* bias_dev, const float* residual_dev, float* out_dev,
                             int M, int N, int K, int act, void* stream) {
-    return launch_gemm32(nullptr, (hipStream_t)stream, a_dev, w_dev, bias_dev, residual_dev, out_dev, M, N, K, act);
+    // act & WM_GEMM32_SPLIT: the fp16-split form (gemm32x3_kernel, W split per K-step); otherwise the fp32-MFMA kernel
+    const int split = (act & WM_GEMM32_SPLIT) != 0;
+    return launch_gemm32(nullptr, (hipStream_t)stream, a_dev, w_dev, bias_dev, residual_dev, out_dev, M, N, K, act & 0xff, 0, split ? 2 : 1);
 }
 
 extern "C" int wm_op_layernorm(const float* x_dev, const float* gamma_dev, const float* beta_dev, float eps, float* out_f32_dev,
