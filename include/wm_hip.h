@@ -256,9 +256,14 @@ int wm_debug_reset_gemm_variant_counts(void);
  * means clamped operands: switch that checkpoint to WM_PREC_BF16 (no clamp, 8-bit mantissa).  Costs one streaming read of
  * each buffer; off by default and absent from timed runs. */
 /* Always on (round 4): the producers of the residual stream's fp16 plane (residual GEMM epilogues, the standalone statistics
- * kernel) set a host-visible word when a stream value reaches the fp16 clamp (|x| >= 65504).  wm_stream_overflow returns 1 if
+ * kernel) set a host-visible word when a stream value reaches the fp16 clamp (|x| >= 65504).  wm_stream_overflow returns WM_OVERFLOW_STREAM if
  * that happened since the last reset (kernels that have finished; no synchronisation), 0 otherwise.  The Python drop-in checks
  * it at every call and warns once: such a checkpoint should run with WM_PREC_BF16. */
+/* The decoder's GEMMs (fp32 values split into fp16 pairs, gemm32.h) raise a second word when an operand leaves fp16's range
+ * (|activation| >= 65504 or |weight| >= 1023; the affected products are inf / nan, not clamped values): WM_GEMM32_F32=1 keeps the fp32 MFMA.
+ * Return value: a mask of the two. */
+#define WM_OVERFLOW_STREAM 1
+#define WM_OVERFLOW_DECODER 2
 int wm_stream_overflow(wm_handle* h, int reset);
 
 #define WM_SAT_LN 0

@@ -646,6 +646,60 @@ def test_fp8_gemm_mask_and_saturation_census(golden_dir):
         hub.saturation_enable(False)
 
 
+def test_overflow_words_are_loud():
+    """The two always-on range watches (wm_stream_overflow): a residual stream that reaches the fp16 clamp (fp16 mode, folded
+    LayerNorm: its operand is the stream itself) and a decoder GEMM operand outside fp16's range (the decoder's GEMMs split fp32
+    values into fp16 pairs).  Clean weights raise neither; each perturbation raises its own bit and the drop-in warns at the next
+    call; the remedy named in the decoder's warning (WM_GEMM32_F32=1) is a process switch; with the weights restored the outputs are
+    bit for bit the clean ones again."""
+    import warnings
+    m, _ = _model("vit_b", "fp16")
+    hub = m._hub
+    x = torch.from_numpy(synth.make_batch(0, 4)).to(G.dev())      # 4 tiles: ViT-B's blocks then run folded (256-row-tile GEMMs)
+    ts = torch.tensor([[1024, 1024]] * 4)
+    m.detect(NestedTensor(x, None), ts)
+    torch.cuda.synchronize()
+    hub.stream_overflow(reset=True)
+    m.detect(NestedTensor(x, None), ts)
+    torch.cuda.synchronize()
+    assert hub.stream_overflow(reset=True) == 0
+    clean_logits = m.detect(NestedTensor(x, None), ts)["pred_logits"].clone()
+    # (1) the stream: a lin2 bias of 1e5 on a few channels
+    bias = m.image_encoder.blocks[3].mlp.lin2.bias
+    keep = bias.detach().clone()
+    with torch.no_grad():
+        bias[:5] += 1.0e5
+    m.detect(NestedTensor(x, None), ts)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        bias.copy_(keep)
+    assert hub.stream_overflow() & 1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.detect(NestedTensor(x, None), ts)
+    assert any("fp16 clamp" in str(i.message) for i in w), [str(i.message) for i in w]
+    torch.cuda.synchronize()
+    assert hub.stream_overflow(reset=True) == 0
+    # (2) the decoder: one weight of 5000 (x 2^6 leaves fp16's range)
+    wt = m.mask_decoder.transformer.layers[0].self_attn.q_proj.weight       # (not the MLP's lin1: its ReLU turns a nan into 0)
+    keepw = wt.detach().clone()
+    with torch.no_grad():
+        wt[3, 7] = 5000.0
+    out = m.detect(NestedTensor(x, None), ts)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        wt.copy_(keepw)
+    assert hub.stream_overflow() & 2
+    # the row is inf / nan inside the decoder; what reaches the logits need not be (softmax and ReLU swallow a nan), but it is wrong
+    assert G.rel_l2(torch.nan_to_num(out["pred_logits"]), clean_logits) > 0.1
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = m.detect(NestedTensor(x, None), ts)
+    assert any("WM_GEMM32_F32" in str(i.message) for i in w), [str(i.message) for i in w]
+    torch.cuda.synchronize()
+    assert hub.stream_overflow(reset=True) == 0 and torch.equal(out["pred_logits"], clean_logits)
+
+
 def test_vit_h_fp8_batch16_vs_reference_golden(golden_dir):
     """configs[4] literally: ViT-H, batch 16, tile 0 = the golden tile."""
     out = _fp8_vs_golden("vit_h", golden_dir, 16)

@@ -712,7 +712,7 @@ int launch_gemm32(wm_handle* h, hipStream_t s, const float* A, const float* W, c
     static const bool f32_only = getenv("WM_GEMM32_F32") && atoi(getenv("WM_GEMM32_F32")) != 0;
     if (mode == 2 && K % 32) return fail("gemm32 (split form): K=%d must be a multiple of 32", K);
     if (mode == 2 || (mode == 0 && h && !f32_only && K % 32 == 0)) {
-        Gemm32x3Args a{A, W, nullptr, nullptr, bias, res, out, M, N, K, act, lda > 0 ? lda : K, h ? h->overflow : nullptr};
+        Gemm32x3Args a{A, W, nullptr, nullptr, bias, res, out, M, N, K, act, lda > 0 ? lda : K, h ? h->overflow + 1 : nullptr};
         if (mode == 0) {                                    // the weight's fp16 planes: made at first use, dropped with the weights
             auto it = h->w32x3.find(W);
             if (it == h->w32x3.end()) {
@@ -720,7 +720,7 @@ int launch_gemm32(wm_handle* h, hipStream_t s, const float* A, const float* W, c
                 const size_t n = (size_t)N * K;
                 if (n % 4) return fail("gemm32: weight of %zu elements", n);
                 WM_TRY(dalloc(h, &hi, n * 2)); WM_TRY(dalloc(h, &lo, n * 2));
-                hipLaunchKernelGGL(split_w32_kernel, dim3(grid_for((int64_t)n / 4)), dim3(256), 0, s, W, (u16*)hi, (u16*)lo, (int64_t)n / 4, h->overflow);
+                hipLaunchKernelGGL(split_w32_kernel, dim3(grid_for((int64_t)n / 4)), dim3(256), 0, s, W, (u16*)hi, (u16*)lo, (int64_t)n / 4, h->overflow + 1);
                 HIP_TRY(hipGetLastError());
                 it = h->w32x3.emplace(W, std::make_pair(hi, lo)).first;
             }
@@ -1274,7 +1274,7 @@ extern "C" int wm_create(const wm_config* cfg, int device, wm_handle** out) {
     if (!r) {
         void* pf = nullptr;
         if (hipHostMalloc(&pf, 64, hipHostMallocMapped) != hipSuccess) r = fail("wm_create: hipHostMalloc failed");
-        else { h->overflow = (int*)pf; *h->overflow = 0; }
+        else { h->overflow = (int*)pf; h->overflow[0] = h->overflow[1] = 0; }       // [0] the fp16 stream, [1] the decoder's fp16-split GEMMs
     }
     if (r) { wm_destroy(h); return r; }
     // FFT twiddles exp(-2 pi i k / 1024), computed in double
@@ -2037,9 +2037,9 @@ extern "C" int wm_profile_read(wm_handle* h, wm_kclass_stat* out) {
 
 extern "C" int wm_stream_overflow(wm_handle* h, int reset) {
     if (!h || !h->overflow) return fail("wm_stream_overflow: null handle");
-    const int v = *(volatile int*)h->overflow;
-    if (reset) *(volatile int*)h->overflow = 0;
-    return v != 0 ? 1 : 0;
+    const int v0 = ((volatile int*)h->overflow)[0], v1 = ((volatile int*)h->overflow)[1];
+    if (reset) ((volatile int*)h->overflow)[0] = ((volatile int*)h->overflow)[1] = 0;
+    return (v0 != 0 ? WM_OVERFLOW_STREAM : 0) | (v1 != 0 ? WM_OVERFLOW_DECODER : 0);
 }
 
 extern "C" int wm_debug_saturation_enable(wm_handle* h, int on) {

@@ -219,16 +219,22 @@ class EngineHub:
             out["records"] = rec
         return out
 
-    def stream_overflow(self, reset: bool = False) -> bool:
-        """True if a value of the residual stream reached the fp16 clamp (|x| >= 65504) in a forward that has finished
-        (wm_stream_overflow; no synchronisation)."""
-        return self._handle is not None and bool(N.lib().wm_stream_overflow(self._handle, int(reset)))
+    def stream_overflow(self, reset: bool = False) -> int:
+        """Non-zero if, in a forward that has finished, a value of the residual stream reached the fp16 clamp (bit 1: |x| >= 65504)
+        or an operand of the decoder's fp16-split GEMMs left fp16's range (bit 2) (wm_stream_overflow; no synchronisation)."""
+        return 0 if self._handle is None else int(N.lib().wm_stream_overflow(self._handle, int(reset)))
 
     def _warn_overflow(self) -> None:
-        if self.stream_overflow(reset=True):
+        v = self.stream_overflow(reset=True)
+        if v:
             import warnings
-            warnings.warn("wildlifemapper_amd: residual-stream values reached the fp16 clamp (|x| >= 65504) in an earlier forward; "
-                          "this checkpoint needs precision='bf16' (WM_PRECISION=bf16)", RuntimeWarning, stacklevel=3)
+            if v & 1:
+                warnings.warn("wildlifemapper_amd: residual-stream values reached the fp16 clamp (|x| >= 65504) in an earlier forward; "
+                              "this checkpoint needs precision='bf16' (WM_PRECISION=bf16)", RuntimeWarning, stacklevel=3)
+            if v & 2:
+                warnings.warn("wildlifemapper_amd: a decoder GEMM operand left fp16's range (|activation| >= 65504 or |weight| >= 1023) in an "
+                              "earlier forward (its products were inf / nan: the detections of that forward are wrong); set WM_GEMM32_F32=1 for the fp32-MFMA decoder GEMMs",
+                              RuntimeWarning, stacklevel=3)
 
     # -- taps / profiling ---------------------------------------------------
     def set_tap(self, which: int) -> None:
