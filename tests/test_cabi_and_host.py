@@ -215,3 +215,24 @@ def test_resize_size_rule_and_coefficients_match_pil_restatement():
         assert ks.value == ks_ref
         assert np.array_equal(np.frombuffer(b, dtype=np.int32).reshape(n_out, 2), b_ref)
         assert np.array_equal(np.frombuffer(k, dtype=np.int32).reshape(n_out, ks_ref), k_ref)
+
+
+def test_plane_pos_is_a_permutation_of_each_256_column_block():
+    """include/wm_hip.h wm_op_stream_rows: the column order of the fp8 blocks' stream planes.  The formula quoted there (and restated in
+    tests/gpu_util.py for the GPU tests) must be a bijection on every 256-column block that keeps aligned groups of 32 columns together
+    (the kernels move 4- and 8-column vectors) and sends the 4 x 32 columns of one residual-epilogue pass to one contiguous run."""
+    import numpy as np
+    for C in (768, 1024, 1280):
+        c = np.arange(C)
+        pos = (c & ~255) + ((c >> 5) & 1) * 128 + ((c >> 6) & 3) * 32 + (c & 31)
+        assert sorted(pos.tolist()) == list(range(C))
+        assert np.array_equal(pos // 256, c // 256)                                   # inside its block
+        assert np.array_equal(pos[::32] % 32, np.zeros(C // 32, dtype=pos.dtype))     # groups of 32 stay aligned ...
+        assert np.array_equal(pos - pos // 32 * 32, c % 32)                           # ... and in order
+        for blk in range(C // 256):
+            for ni in (0, 1):                                                         # a pass: columns 64 strip + 32 ni + (0..31), strip = 0..3
+                cols = np.concatenate([blk * 256 + 64 * strip + 32 * ni + np.arange(32) for strip in range(4)])
+                p = np.sort(pos[cols])
+                assert np.array_equal(p, np.arange(p[0], p[0] + 128)), (C, blk, ni)
+        inv = (pos & ~255) + ((pos >> 5) & 3) * 64 + ((pos >> 7) & 1) * 32 + (pos & 31)   # wm::plane_col (csrc/wm_common.h)
+        assert np.array_equal(inv, c)

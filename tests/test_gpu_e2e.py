@@ -592,6 +592,21 @@ def test_fp8_stream_planes_against_fp32_stream():
     assert errs["mid-block tap"] < 4e-2 and errs["last-block tap"] < 4e-2 and errs["logits"] < 3e-3, errs
 
 
+def test_fp8_planes_with_bf16_head_and_tail_blocks(golden_dir):
+    """The plane form of the fp8 blocks' stream next to blocks of another operand type (WM_FP8_BF16_HEAD / TAIL: the first / last K
+    blocks run bf16 on the fp32 stream): fp32 -> planes in front of the first fp8 block, planes -> fp32 behind the last, the neck fed
+    from fp32.  Same bounds as the all-fp8 run; the instance counters show 2 plane GEMMs per fp8 block and none for the others."""
+    m, _ = _model("vit_b", "fp16")
+    try:
+        os.environ["WM_FP8_BF16_HEAD"], os.environ["WM_FP8_BF16_TAIL"] = "1", "2"
+        m._hub.set_precision("fp16")                          # the next fp8 handle reads the switches
+        _fp8_vs_golden("vit_b", golden_dir, 2)
+    finally:
+        os.environ.pop("WM_FP8_BF16_HEAD", None)
+        os.environ.pop("WM_FP8_BF16_TAIL", None)
+        m._hub.set_precision("fp16")
+
+
 def test_fp8_gemm_mask_and_saturation_census(golden_dir):
     """wm_config.fp8_gemms (round 3): ViT-B with only the MLP pair on the fp8 MFMA (qkv / proj / attention bf16).  The GEMM
     instance counters show the mix; its logits error lies between bf16's and all-fp8's.  Then the saturation census
